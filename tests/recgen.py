@@ -1,0 +1,124 @@
+"""Seeded builders of macroblock-record pictures for the parity tests (numpy RNG).
+
+These make inputs only; expected outputs always come from the oracle.
+"""
+import numpy as np
+
+from oracle.oracle import MB_RECORD_DTYPE
+from oracle.np_restatement import ZIGZAG_RASTER
+
+INTER, INTERQ, INTER4V, INTRA, INTRAQ, INTER4VQ = range(6)
+BLOCK_CLASSES = ("dc", "horiz", "vert", "full_dense", "full_sparse")
+
+
+def mb_dims(w, h):
+    return (w + 15) // 16, (h + 15) // 16
+
+
+def random_intradc(rng, n):
+    c = rng.integers(1, 255, n)        # 1..254
+    c[c == 128] = 129
+    return c.astype(np.uint8)
+
+
+def fill_block(rng, cls, max_level=127, intra=True):
+    """int16[64] raster coefficient block of the requested class."""
+    c = np.zeros(64, np.int16)
+
+    def lv(n):
+        v = rng.integers(1, max_level + 1, n) * rng.choice([-1, 1], n)
+        return v.astype(np.int16)
+
+    if cls == "horiz":
+        pos = np.arange(1, 8)
+        pos = pos[rng.random(7) < 0.7]
+        if pos.size == 0:
+            pos = np.array([1])
+        c[pos] = lv(pos.size)
+    elif cls == "vert":
+        pos = np.arange(1, 8) * 8
+        pos = pos[rng.random(7) < 0.7]
+        if pos.size == 0:
+            pos = np.array([8])
+        c[pos] = lv(pos.size)
+    elif cls == "full_dense":
+        c[1:] = lv(63)
+        if not intra:
+            c[0] = lv(1)[0]
+    elif cls == "full_sparse":
+        pos = rng.choice(np.arange(0 if not intra else 1, 64), 4, replace=False)
+        c[pos] = lv(4)
+    elif cls == "dc_coeff":              # inter block whose only coefficient sits at zigzag 0
+        c[0] = lv(1)[0]
+    return c
+
+
+def intra_picture(w, h, seed, classes=BLOCK_CLASSES, max_level=127, quant=None, n_mbs=None):
+    """All-intra picture (config 1 / config 2 'mixed'); returns (mbs, coeffs)."""
+    rng = np.random.default_rng(seed)
+    mbw, mbh = mb_dims(w, h)
+    n = mbw * mbh if n_mbs is None else n_mbs
+    mbs = np.zeros(n, MB_RECORD_DTYPE)
+    coeffs = []
+    for i in range(n):
+        m = mbs[i]
+        m["mb_type"] = INTRA if rng.random() < 0.8 else INTRAQ
+        m["quant"] = quant if quant else rng.integers(1, 32)
+        m["intradc"] = random_intradc(rng, 6)
+        m["coeff_index"] = len(coeffs)
+        cbp = 0
+        for b in range(6):
+            cls = classes[rng.integers(0, len(classes))]
+            if cls == "dc":
+                continue
+            cbp |= 1 << b
+            # keep q*(2|L|+1) inside i16 (SURVEY 8a1 contract)
+            coeffs.append(fill_block(rng, cls, max_level, intra=True))
+        m["cbp"] = cbp
+    c = np.array(coeffs, np.int16).reshape(-1, 64) if coeffs else np.zeros((0, 64), np.int16)
+    return mbs, c
+
+
+def inter_picture(w, h, seed, mv_range=32, p_coded=0.25, p_4v=0.1, p_intra=0.0, quant=10,
+                  max_level=31, n_mbs=None, sparse_low=True):
+    """P picture (config 3): random half-pel MVs, sparse residuals; returns (mbs, coeffs)."""
+    rng = np.random.default_rng(seed)
+    mbw, mbh = mb_dims(w, h)
+    n = mbw * mbh if n_mbs is None else n_mbs
+    mbs = np.zeros(n, MB_RECORD_DTYPE)
+    coeffs = []
+    for i in range(n):
+        m = mbs[i]
+        intra = rng.random() < p_intra
+        m["quant"] = quant if quant else rng.integers(1, 32)
+        m["coeff_index"] = len(coeffs)
+        if intra:
+            m["mb_type"] = INTRA
+            m["intradc"] = random_intradc(rng, 6)
+        else:
+            four = rng.random() < p_4v
+            m["mb_type"] = INTER4V if four else INTER
+            if four:
+                m["mv"] = rng.integers(-mv_range, mv_range, (4, 2))
+            else:
+                m["mv"] = np.tile(rng.integers(-mv_range, mv_range, (1, 2)), (4, 1))
+        cbp = 0
+        for b in range(6):
+            if rng.random() >= p_coded:
+                continue
+            cbp |= 1 << b
+            c = np.zeros(64, np.int16)
+            lo = 1 if intra else 0
+            zz = rng.choice(np.arange(lo, 16 if sparse_low else 64), 4, replace=False)
+            c[ZIGZAG_RASTER[zz]] = (rng.integers(1, max_level + 1, 4) * rng.choice([-1, 1], 4)).astype(np.int16)
+            coeffs.append(c)
+        m["cbp"] = cbp
+    c = np.array(coeffs, np.int16).reshape(-1, 64) if coeffs else np.zeros((0, 64), np.int16)
+    return mbs, c
+
+
+def random_planes(w, h, seed):
+    rng = np.random.default_rng(seed)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    return (rng.integers(0, 256, w * h, dtype=np.uint8), rng.integers(0, 256, cw * ch, dtype=np.uint8),
+            rng.integers(0, 256, cw * ch, dtype=np.uint8))

@@ -1,0 +1,792 @@
+// backend.cpp -- host side of the C ABI (include/h263mi.h): device-resident frame store,
+// batch of streams, the H263State mirror, and the plain-function deblock / bt601 entry
+// points.  Compiled with hipcc; every compute path launches the gfx950 kernels of
+// kernels.hip -- there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+#include "post_kernel.inl"   // tile constants only
+#include "recon_kernel.inl"  // tile constants only
+#include "synth.inl"
+
+using namespace h263mi;
+
+namespace {
+
+int map_hip_error(hipError_t e)
+{
+    switch (e) {
+    case hipSuccess: return H263MI_OK;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice:
+    case hipErrorInsufficientDriver:
+    case hipErrorNotInitialized: return H263MI_ERR_NO_DEVICE;
+    case hipErrorOutOfMemory: return H263MI_ERR_OUT_OF_MEMORY;
+    default: return H263MI_ERR_HIP;
+    }
+}
+
+#define HIP_TRY(expr)                                    \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return map_hip_error(_e);  \
+    } while (0)
+
+#define RC_TRY(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != H263MI_OK) return _rc; \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
+uint32_t recon_tiles_y(const FrameLayout &L) { return (L.mbh + TILE_MBY - 1) / TILE_MBY; }
+uint32_t post_tiles_x(const FrameLayout &L) { return (L.width + POST_OX + POST_TW - 1) / POST_TW; }
+uint32_t post_tiles_y(const FrameLayout &L) { return (L.height + POST_OY + POST_TH - 1) / POST_TH; }
+
+}  // namespace
+
+// =========================================================================================
+// batch of streams
+// =========================================================================================
+struct h263mi_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n = 0;
+    FrameLayout L{};
+    uint8_t *frames[2] = {nullptr, nullptr};   // ping-pong frame sets, n * frame_bytes each
+    int cur = -1;                              // frame set holding the last picture, -1 = none
+    bool has_ref = false;                      // state.rs:29-31 reference_picture.is_some()
+    uint32_t *d_status = nullptr;
+    uint32_t *h_status = nullptr;              // pinned
+    uint64_t coeff_pool_blocks = 0;            // 0 = unchecked
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, int>> ev_ranges;   // (index of start event, kernel id)
+
+    int alloc(uint32_t n_streams, uint32_t w, uint32_t h)
+    {
+        n = n_streams;
+        L = make_layout(w, h);
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipMalloc((void **)&frames[i], (size_t)n * L.frame_bytes));
+            HIP_TRY(hipMemsetAsync(frames[i], 0, (size_t)n * L.frame_bytes, stream));
+        }
+        if (!d_status) {
+            HIP_TRY(hipMalloc((void **)&d_status, sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t), hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+        cur = -1;
+        has_ref = false;
+        return H263MI_OK;
+    }
+
+    void release_frames()
+    {
+        for (int i = 0; i < 2; i++) {
+            if (frames[i]) (void)hipFree(frames[i]);
+            frames[i] = nullptr;
+        }
+    }
+
+    ~h263mi_batch()
+    {
+        DeviceGuard g(device);
+        (void)hipStreamSynchronize(stream);
+        release_frames();
+        if (d_status) (void)hipFree(d_status);
+        if (h_status) (void)hipHostFree(h_status);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    }
+
+    int time_begin(int kernel_id)
+    {
+        if (!timing) return H263MI_OK;
+        if (ev_used + 2 > ev_pool.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                ev_pool.push_back(e);
+            }
+        }
+        ev_ranges.emplace_back(ev_used, kernel_id);
+        HIP_TRY(hipEventRecord(ev_pool[ev_used], stream));
+        return H263MI_OK;
+    }
+    int time_end()
+    {
+        if (!timing) return H263MI_OK;
+        HIP_TRY(hipEventRecord(ev_pool[ev_used + 1], stream));
+        ev_used += 2;
+        return H263MI_OK;
+    }
+
+    // state.rs:432-483 for every stream of the batch
+    int submit(uint8_t picture_type, const MbRecord *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base)
+    {
+        const int out = cur < 0 ? 0 : (cur ^ 1);
+        ReconArgs a{};
+        a.L = L;
+        a.mbs = d_mbs;
+        a.coeffs = d_coeffs;
+        a.coeff_base = d_coeff_base;
+        // get_reference_picture() hands out the LAST picture whenever a reference exists (state.rs:72-78)
+        a.ref = frames[cur < 0 ? 1 : cur];
+        a.cur = frames[out];
+        a.status = d_status;
+        a.coeff_pool_blocks = coeff_pool_blocks;
+        a.n_pictures = n;
+        a.mbs_per_picture = L.mbw * L.mbh;
+        a.has_ref = (has_ref && cur >= 0) ? 1u : 0u;
+        a.tiles_x = recon_tiles_x(L);
+        a.tiles_y = recon_tiles_y(L);
+        RC_TRY(time_begin(0));
+        HIP_TRY(launch_recon(a, stream));
+        RC_TRY(time_end());
+        // reference bookkeeping, state.rs:464-483
+        if (picture_type == H263MI_PICTURE_I) has_ref = false;
+        cur = out;
+        if (picture_type != H263MI_PICTURE_DISPOSABLE_P) has_ref = true;
+        return H263MI_OK;
+    }
+
+    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
+    {
+        if (cur < 0) return H263MI_ERR_NO_PICTURE;
+        if (strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
+        PostArgs a{};
+        a.L = L;
+        a.frames = frames[cur];
+        a.rgba = d_rgba;
+        a.planes_out = d_planes;
+        a.n_pictures = n;
+        a.strength = strength;
+        a.tiles_x = post_tiles_x(L);
+        a.tiles_y = post_tiles_y(L);
+        a.luma_only = 0;
+        RC_TRY(time_begin(1));
+        HIP_TRY(launch_post(a, stream));
+        RC_TRY(time_end());
+        return H263MI_OK;
+    }
+
+    int sync()
+    {
+        HIP_TRY(hipMemcpyAsync(h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        uint32_t st = *h_status;
+        if (st) {
+            HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+            if (st & STATUS_INTER_WITHOUT_REFERENCE) return H263MI_ERR_UNCODED_IFRAME_BLOCKS;
+            return H263MI_ERR_INVALID_ARGUMENT;
+        }
+        return H263MI_OK;
+    }
+
+    int copy_yuv(uint32_t s, uint8_t *y, uint8_t *cb, uint8_t *cr)
+    {
+        if (cur < 0) return H263MI_ERR_NO_PICTURE;
+        if (s >= n) return H263MI_ERR_INVALID_ARGUMENT;
+        const uint8_t *f = frames[cur] + (size_t)s * L.frame_bytes;
+        // DecodedPicture planes are exact-size and tightly packed (picture.rs:39-58)
+        if (y) HIP_TRY(hipMemcpy2DAsync(y, L.width, f, L.pitch_y, L.width, L.height, hipMemcpyDeviceToHost, stream));
+        if (cb) HIP_TRY(hipMemcpy2DAsync(cb, L.cwidth, f + L.off_cb, L.pitch_c, L.cwidth, L.cheight, hipMemcpyDeviceToHost, stream));
+        if (cr) HIP_TRY(hipMemcpy2DAsync(cr, L.cwidth, f + L.off_cr, L.pitch_c, L.cwidth, L.cheight, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return H263MI_OK;
+    }
+};
+
+static int check_device(int device_id)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return H263MI_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return H263MI_ERR_NO_DEVICE;
+    return H263MI_OK;
+}
+
+static int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi_backend_cfg *cfg, h263mi_batch **out)
+{
+    if (!out || !n_streams || !w || !h) return H263MI_ERR_INVALID_ARGUMENT;
+    const int dev = cfg ? cfg->device_id : 0;
+    RC_TRY(check_device(dev));
+    DeviceGuard g(dev);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    h263mi_batch *b = new (std::nothrow) h263mi_batch();
+    if (!b) return H263MI_ERR_OUT_OF_MEMORY;
+    b->device = dev;
+    b->stream = cfg ? (hipStream_t)cfg->stream : nullptr;
+    int rc = b->alloc(n_streams, w, h);
+    if (rc != H263MI_OK) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return H263MI_OK;
+}
+
+// =========================================================================================
+// H263State mirror: a batch of one stream fed with host records
+// =========================================================================================
+struct h263mi_state {
+    uint32_t options = 0;
+    h263mi_backend_cfg cfg{};
+    h263mi_batch *b = nullptr;
+    h263mi_picture_desc last_desc{};
+    bool has_last = false;
+    // staging
+    MbRecord *h_mbs = nullptr;  int16_t *h_coeffs = nullptr;     // pinned
+    MbRecord *d_mbs = nullptr;  int16_t *d_coeffs = nullptr;
+    size_t cap_mbs = 0, cap_blocks = 0;
+    uint8_t *d_rgba = nullptr;  size_t cap_rgba = 0;
+    hipEvent_t staged = nullptr;
+
+    void free_staging()
+    {
+        if (h_mbs) (void)hipHostFree(h_mbs);
+        if (h_coeffs) (void)hipHostFree(h_coeffs);
+        if (d_mbs) (void)hipFree(d_mbs);
+        if (d_coeffs) (void)hipFree(d_coeffs);
+        if (d_rgba) (void)hipFree(d_rgba);
+        h_mbs = nullptr; h_coeffs = nullptr; d_mbs = nullptr; d_coeffs = nullptr; d_rgba = nullptr;
+        cap_mbs = cap_blocks = cap_rgba = 0;
+    }
+    ~h263mi_state()
+    {
+        DeviceGuard g(cfg.device_id);
+        if (b) (void)hipStreamSynchronize(b->stream);
+        free_staging();
+        if (staged) (void)hipEventDestroy(staged);
+        delete b;
+    }
+};
+
+static int state_ensure_staging(h263mi_state *s, size_t n_mbs, size_t n_blocks)
+{
+    if (n_mbs > s->cap_mbs) {
+        if (s->h_mbs) (void)hipHostFree(s->h_mbs);
+        if (s->d_mbs) (void)hipFree(s->d_mbs);
+        s->h_mbs = nullptr; s->d_mbs = nullptr; s->cap_mbs = 0;
+        HIP_TRY(hipHostMalloc((void **)&s->h_mbs, n_mbs * sizeof(MbRecord), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&s->d_mbs, n_mbs * sizeof(MbRecord)));
+        s->cap_mbs = n_mbs;
+    }
+    if (n_blocks > s->cap_blocks) {
+        if (s->h_coeffs) (void)hipHostFree(s->h_coeffs);
+        if (s->d_coeffs) (void)hipFree(s->d_coeffs);
+        s->h_coeffs = nullptr; s->d_coeffs = nullptr; s->cap_blocks = 0;
+        size_t cap = n_blocks + n_blocks / 2 + 64;
+        HIP_TRY(hipHostMalloc((void **)&s->h_coeffs, cap * 128, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&s->d_coeffs, cap * 128));
+        s->cap_blocks = cap;
+    }
+    return H263MI_OK;
+}
+
+extern "C" {
+
+const uint8_t h263mi_quant_to_strength[32] = {0, 1, 1, 2, 2, 3, 3, 4, 4, 4,  5,  5,  6,  6,  7,  7,
+                                              7, 8, 8, 8, 9, 9, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12};
+
+int h263mi_abi_version(void) { return H263MI_ABI_VERSION; }
+
+const char *h263mi_strerror(int code)
+{
+    switch (code) {
+    case H263MI_OK: return "ok";
+    case H263MI_ERR_INTERNAL_DECODER_ERROR: return "the H.263 decoder failed internally, this is a bug";
+    case H263MI_ERR_MIDDLE_OF_BITSTREAM: return "the H.263 bitstream doesn't start with a picture";
+    case H263MI_ERR_INVALID_MACROBLOCK_HEADER: return "the H.263 bitstream contains an invalid macroblock header";
+    case H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS: return "the H.263 bitstream contains invalid macroblock coded bits";
+    case H263MI_ERR_INVALID_INTRA_DC: return "the H.263 bitstream contains an invalid intra-dc coefficient";
+    case H263MI_ERR_INVALID_SHORT_COEFFICIENT: return "the H.263 bitstream contains an invalid short ac coefficient";
+    case H263MI_ERR_INVALID_LONG_COEFFICIENT: return "the H.263 bitstream contains an invalid long ac coefficient";
+    case H263MI_ERR_INVALID_MVD: return "the H.263 bitstream contains an invalid motion vector";
+    case H263MI_ERR_INVALID_PTYPE: return "the H.263 bitstream has an invalid picture type";
+    case H263MI_ERR_INVALID_PLUS_PTYPE: return "the H.263 bitstream has an invalid extension picture type";
+    case H263MI_ERR_INVALID_GOB_HEADER: return "the H.263 bitstream has an invalid group-of-blocks header";
+    case H263MI_ERR_INVALID_BITSTREAM: return "the H.263 bitstream could not be decoded";
+    case H263MI_ERR_PICTURE_FORMAT_MISSING: return "the decoded H.263 bitstream is missing it's picture format";
+    case H263MI_ERR_PICTURE_FORMAT_INVALID: return "the decoded H.263 bitstream has an invalid picture format";
+    case H263MI_ERR_UNCODED_IFRAME_BLOCKS: return "the decoded H.263 bitstream has uncoded iframe blocks";
+    case H263MI_ERR_UNHANDLED_IO_ERROR: return "an I/O error occured";
+    case H263MI_ERR_UNIMPLEMENTED_DECODING: return "a feature in the H.263 bitstream being decoded is not yet supported";
+    case H263MI_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case H263MI_ERR_NO_DEVICE: return "no usable HIP device (the MI355X back-end has no CPU fallback)";
+    case H263MI_ERR_HIP: return "HIP runtime error";
+    case H263MI_ERR_OUT_OF_MEMORY: return "out of memory";
+    case H263MI_ERR_NO_PICTURE: return "no picture has been decoded yet";
+    default: return "unknown error";
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// batch API
+// ---------------------------------------------------------------------------------------
+int h263mi_batch_create(uint32_t n_streams, uint16_t width, uint16_t height, const h263mi_backend_cfg *cfg,
+                        h263mi_batch **out)
+{
+    return batch_create(n_streams, width, height, cfg, out);
+}
+
+void h263mi_batch_destroy(h263mi_batch *b) { delete b; }
+
+uint32_t h263mi_batch_mbs_per_picture(const h263mi_batch *b) { return b ? b->L.mbw * b->L.mbh : 0; }
+
+int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs, const int16_t *d_coeffs,
+                        const uint64_t *d_coeff_base)
+{
+    if (!b || !d_mbs || picture_type > H263MI_PICTURE_DISPOSABLE_P) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    return b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base);
+}
+
+int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)
+{
+    if (!b || (!d_rgba && !d_deblocked)) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    return b->render(strength, d_rgba, d_deblocked);
+}
+
+int h263mi_batch_sync(h263mi_batch *b)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    return b->sync();
+}
+
+int h263mi_batch_reset(h263mi_batch *b)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    b->cur = -1;
+    b->has_ref = false;
+    return H263MI_OK;
+}
+
+int h263mi_batch_copy_yuv(h263mi_batch *b, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    return b->copy_yuv(stream, y, cb, cr);
+}
+
+int h263mi_batch_timing_begin(h263mi_batch *b)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    b->timing = true;
+    b->ev_used = 0;
+    b->ev_ranges.clear();
+    return H263MI_OK;
+}
+
+int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out)
+{
+    if (!b || !out) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    b->timing = false;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    *out = h263mi_kernel_times{};
+    for (auto &r : b->ev_ranges) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev_pool[r.first], b->ev_pool[r.first + 1]));
+        if (r.second == 0) {
+            out->recon_ms += ms;
+            out->recon_launches++;
+        } else {
+            out->post_ms += ms;
+            out->post_launches++;
+        }
+    }
+    b->ev_ranges.clear();
+    b->ev_used = 0;
+    return H263MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// H263State
+// ---------------------------------------------------------------------------------------
+int h263mi_state_new(uint32_t decoder_options, const h263mi_backend_cfg *cfg, h263mi_state **out)
+{
+    if (!out) return H263MI_ERR_INVALID_ARGUMENT;
+    const int dev = cfg ? cfg->device_id : 0;
+    RC_TRY(check_device(dev));
+    h263mi_state *s = new (std::nothrow) h263mi_state();
+    if (!s) return H263MI_ERR_OUT_OF_MEMORY;
+    s->options = decoder_options;
+    if (cfg) s->cfg = *cfg;
+    s->cfg.device_id = dev;
+    *out = s;
+    return H263MI_OK;
+}
+
+void h263mi_state_free(h263mi_state *s) { delete s; }
+
+int h263mi_state_is_sorenson(const h263mi_state *s) { return s && (s->options & H263MI_SORENSON_SPARK_BITSTREAM) ? 1 : 0; }
+
+int h263mi_state_reset(h263mi_state *s)
+{
+    if (!s) return H263MI_ERR_INVALID_ARGUMENT;
+    s->has_last = false;
+    if (s->b) {
+        s->b->cur = -1;
+        s->b->has_ref = false;
+    }
+    return H263MI_OK;
+}
+
+int h263mi_state_cleanup_buffers(h263mi_state *s)
+{
+    // The store never holds more than the last and the reference picture (two frame sets),
+    // which is exactly what cleanup_buffers (state.rs:81-98) leaves behind.
+    return s ? H263MI_OK : H263MI_ERR_INVALID_ARGUMENT;
+}
+
+int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
+                          const int16_t *coeffs, size_t n_coeff_blocks)
+{
+    if (!s || !desc || (!mbs && n_mbs) || (!coeffs && n_coeff_blocks)) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!desc->width || !desc->height) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+    if (desc->picture_type > H263MI_PICTURE_DISPOSABLE_P) return H263MI_ERR_INVALID_ARGUMENT;
+    const FrameLayout L = make_layout(desc->width, desc->height);
+    const size_t total = (size_t)L.mbw * L.mbh;
+    if (n_mbs > total) return H263MI_ERR_INVALID_ARGUMENT;
+
+    // ---- everything that can fail is checked before any state changes (state.rs:142, 464-487)
+    bool any_inter = n_mbs < total;   // missing macroblocks are padded as Inter (state.rs:421-427)
+    for (size_t i = 0; i < n_mbs; i++) {
+        const h263mi_mb_record &m = mbs[i];
+        if (m.mb_type > H263MI_MB_INTER4V_Q || m.quant < 1 || m.quant > 31 || (m.cbp & 0xC0) || (m.kill & 0xC0))
+            return H263MI_ERR_INVALID_ARGUMENT;
+        if (mb_is_inter(m.mb_type)) any_inter = true;
+        if ((size_t)m.coeff_index + (size_t)__builtin_popcount(m.cbp) > n_coeff_blocks) return H263MI_ERR_INVALID_ARGUMENT;
+    }
+    const bool same_size = s->b && s->b->L.width == L.width && s->b->L.height == L.height;
+    const bool has_ref = s->b && s->b->has_ref && s->b->cur >= 0;
+    if (any_inter && !has_ref) return H263MI_ERR_UNCODED_IFRAME_BLOCKS;              // gather.rs:149
+    // A size change under inter prediction indexes the new planes with the reference's strides in
+    // the reference (gather.rs:150,183: out-of-bounds panic or garbage); reported as an error here.
+    if (any_inter && !same_size) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+
+    DeviceGuard g(s->cfg.device_id);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    if (!same_size) {
+        h263mi_batch *nb = nullptr;
+        RC_TRY(batch_create(1, L.width, L.height, &s->cfg, &nb));
+        delete s->b;
+        s->b = nb;
+        s->has_last = false;
+    }
+    h263mi_batch *b = s->b;
+    RC_TRY(state_ensure_staging(s, total, n_coeff_blocks ? n_coeff_blocks : 1));
+    if (!s->staged) HIP_TRY(hipEventCreateWithFlags(&s->staged, hipEventDisableTiming));
+    HIP_TRY(hipEventSynchronize(s->staged));     // previous upload finished: staging is reusable
+
+    memcpy(s->h_mbs, mbs, n_mbs * sizeof(MbRecord));
+    for (size_t i = n_mbs; i < total; i++) {     // state.rs:421-427: Inter, mv (0,0), nothing coded
+        MbRecord pad;
+        memset(&pad, 0, sizeof pad);
+        pad.mb_type = H263MI_MB_INTER;
+        pad.quant = 1;
+        s->h_mbs[i] = pad;
+    }
+    if (n_coeff_blocks) memcpy(s->h_coeffs, coeffs, n_coeff_blocks * 128);
+    HIP_TRY(hipMemcpyAsync(s->d_mbs, s->h_mbs, total * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
+    if (n_coeff_blocks)
+        HIP_TRY(hipMemcpyAsync(s->d_coeffs, s->h_coeffs, n_coeff_blocks * 128, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipEventRecord(s->staged, b->stream));
+
+    b->coeff_pool_blocks = n_coeff_blocks;
+    RC_TRY(b->submit(desc->picture_type, s->d_mbs, s->d_coeffs, nullptr));
+    s->last_desc = *desc;
+    s->has_last = true;
+    return H263MI_OK;
+}
+
+int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len, size_t *consumed)
+{
+    (void)data; (void)len; (void)consumed;
+    if (!s) return H263MI_ERR_INVALID_ARGUMENT;
+    return H263MI_ERR_UNIMPLEMENTED_DECODING;   // host bitstream parser: SURVEY section 8 row f-1
+}
+
+static int fill_view(const h263mi_state *s, h263mi_frame_view *out)
+{
+    const h263mi_batch *b = s->b;
+    const uint8_t *f = b->frames[b->cur];
+    memset(out, 0, sizeof *out);
+    out->width = (uint16_t)b->L.width;
+    out->height = (uint16_t)b->L.height;
+    out->chroma_width = (uint16_t)b->L.cwidth;
+    out->chroma_height = (uint16_t)b->L.cheight;
+    out->temporal_reference = s->last_desc.temporal_reference;
+    out->picture_type = s->last_desc.picture_type;
+    out->pquant = s->last_desc.pquant;
+    out->use_deblocker = s->last_desc.use_deblocker;
+    out->dev_y = f;
+    out->dev_cb = f + b->L.off_cb;
+    out->dev_cr = f + b->L.off_cr;
+    out->dev_pitch_y = b->L.pitch_y;
+    out->dev_pitch_c = b->L.pitch_c;
+    return H263MI_OK;
+}
+
+int h263mi_get_last_picture(const h263mi_state *s, h263mi_frame_view *out)
+{
+    if (!s || !out) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!s->has_last || !s->b || s->b->cur < 0) return H263MI_ERR_NO_PICTURE;
+    return fill_view(s, out);
+}
+
+int h263mi_get_reference_picture(const h263mi_state *s, h263mi_frame_view *out)
+{
+    if (!s || !out) return H263MI_ERR_INVALID_ARGUMENT;
+    // state.rs:72-78: None without a reference, otherwise the entry of *last_picture*
+    if (!s->has_last || !s->b || s->b->cur < 0 || !s->b->has_ref) return H263MI_ERR_NO_PICTURE;
+    return fill_view(s, out);
+}
+
+int h263mi_copy_yuv(const h263mi_state *s, uint8_t *y, uint8_t *cb, uint8_t *cr)
+{
+    if (!s) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!s->has_last || !s->b) return H263MI_ERR_NO_PICTURE;
+    DeviceGuard g(s->cfg.device_id);
+    return s->b->copy_yuv(0, y, cb, cr);
+}
+
+int h263mi_render_rgba(const h263mi_state *cs, uint8_t strength, uint8_t *rgba)
+{
+    h263mi_state *s = const_cast<h263mi_state *>(cs);
+    if (!s || !rgba) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!s->has_last || !s->b) return H263MI_ERR_NO_PICTURE;
+    DeviceGuard g(s->cfg.device_id);
+    h263mi_batch *b = s->b;
+    const size_t bytes = (size_t)b->L.width * b->L.height * 4;
+    if (bytes > s->cap_rgba) {
+        if (s->d_rgba) (void)hipFree(s->d_rgba);
+        s->d_rgba = nullptr; s->cap_rgba = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_rgba, bytes));
+        s->cap_rgba = bytes;
+    }
+    RC_TRY(b->render(strength, s->d_rgba, nullptr));
+    HIP_TRY(hipMemcpyAsync(rgba, s->d_rgba, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return H263MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// deblock::deblock and yuv::bt601::yuv420_to_rgba as plain functions over host buffers
+// ---------------------------------------------------------------------------------------
+struct TempBuf {
+    void *p = nullptr;
+    ~TempBuf() { if (p) (void)hipFree(p); }
+};
+
+int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out)
+{
+    // preconditions of deblock.rs:30,306 (debug_asserts in the reference)
+    if (!data || !out || !width || len % width != 0 || strength < 1 || strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
+    const size_t height = len / width;
+    if (!height || width > 65535 || height > 65535) return H263MI_ERR_INVALID_ARGUMENT;
+    RC_TRY(check_device(0));
+    DeviceGuard g(0);
+    const FrameLayout L = make_layout((uint32_t)width, (uint32_t)height);
+    TempBuf frame, planes;
+    HIP_TRY(hipMalloc(&frame.p, L.frame_bytes));
+    HIP_TRY(hipMalloc(&planes.p, len));
+    HIP_TRY(hipMemset(frame.p, 0, L.frame_bytes));
+    HIP_TRY(hipMemcpy2D(frame.p, L.pitch_y, data, width, width, height, hipMemcpyHostToDevice));
+    PostArgs a{};
+    a.L = L;
+    a.L.cwidth = a.L.cheight = 0;
+    a.frames = (const uint8_t *)frame.p;
+    a.rgba = nullptr;
+    a.planes_out = (uint8_t *)planes.p;
+    a.n_pictures = 1;
+    a.strength = strength;
+    a.tiles_x = post_tiles_x(L);
+    a.tiles_y = post_tiles_y(L);
+    a.luma_only = 1;
+    HIP_TRY(launch_post(a, nullptr));
+    HIP_TRY(hipMemcpy(out, planes.p, len, hipMemcpyDeviceToHost));
+    return H263MI_OK;
+}
+
+int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len, const uint8_t *chroma_b, const uint8_t *chroma_r,
+                                size_t c_len, size_t y_width, uint8_t *rgba_out)
+{
+    if (y_len == 0) return H263MI_OK;                       // bt601.rs:107-112: empty in, empty out
+    if (!y || !chroma_b || !chroma_r || !rgba_out || !y_width || y_len % y_width != 0) return H263MI_ERR_INVALID_ARGUMENT;
+    const size_t h = y_len / y_width, cw = (y_width + 1) / 2, ch = (h + 1) / 2;   // bt601.rs:115-126
+    if (c_len != cw * ch || y_width > 65535 || h > 65535) return H263MI_ERR_INVALID_ARGUMENT;
+    RC_TRY(check_device(0));
+    DeviceGuard g(0);
+    const FrameLayout L = make_layout((uint32_t)y_width, (uint32_t)h);
+    TempBuf frame, rgba;
+    HIP_TRY(hipMalloc(&frame.p, L.frame_bytes));
+    HIP_TRY(hipMalloc(&rgba.p, y_len * 4));
+    HIP_TRY(hipMemset(frame.p, 0, L.frame_bytes));
+    uint8_t *f = (uint8_t *)frame.p;
+    HIP_TRY(hipMemcpy2D(f, L.pitch_y, y, y_width, y_width, h, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(f + L.off_cb, L.pitch_c, chroma_b, cw, cw, ch, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(f + L.off_cr, L.pitch_c, chroma_r, cw, cw, ch, hipMemcpyHostToDevice));
+    PostArgs a{};
+    a.L = L;
+    a.frames = f;
+    a.rgba = (uint8_t *)rgba.p;
+    a.planes_out = nullptr;
+    a.n_pictures = 1;
+    a.strength = 0;
+    a.tiles_x = post_tiles_x(L);
+    a.tiles_y = post_tiles_y(L);
+    a.luma_only = 0;
+    HIP_TRY(launch_post(a, nullptr));
+    HIP_TRY(hipMemcpy(rgba_out, rgba.p, y_len * 4, hipMemcpyDeviceToHost));
+    return H263MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// device memory helpers + synthetic records
+// ---------------------------------------------------------------------------------------
+int h263mi_device_count(int *count)
+{
+    if (!count) return H263MI_ERR_INVALID_ARGUMENT;
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return H263MI_ERR_NO_DEVICE;
+    }
+    return H263MI_OK;
+}
+
+int h263mi_device_malloc(int device_id, size_t bytes, void **out)
+{
+    if (!out) return H263MI_ERR_INVALID_ARGUMENT;
+    RC_TRY(check_device(device_id));
+    DeviceGuard g(device_id);
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return H263MI_OK;
+}
+
+int h263mi_device_free(int device_id, void *p)
+{
+    RC_TRY(check_device(device_id));
+    DeviceGuard g(device_id);
+    HIP_TRY(hipFree(p));
+    return H263MI_OK;
+}
+
+int h263mi_device_memcpy_h2d(int device_id, void *dst, const void *src, size_t bytes)
+{
+    RC_TRY(check_device(device_id));
+    DeviceGuard g(device_id);
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return H263MI_OK;
+}
+
+int h263mi_device_memcpy_d2h(int device_id, void *dst, const void *src, size_t bytes)
+{
+    RC_TRY(check_device(device_id));
+    DeviceGuard g(device_id);
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return H263MI_OK;
+}
+
+int h263mi_device_synchronize(int device_id)
+{
+    RC_TRY(check_device(device_id));
+    DeviceGuard g(device_id);
+    HIP_TRY(hipDeviceSynchronize());
+    return H263MI_OK;
+}
+
+int h263mi_synth_picture_host(int kind, uint16_t width, uint16_t height, uint32_t stream_id, uint32_t frame_idx,
+                              h263mi_mb_record *mbs, int16_t *coeffs, size_t coeff_capacity_blocks,
+                              size_t *n_coeff_blocks)
+{
+    if (kind < 0 || kind > H263MI_SYNTH_P || !width || !height || !mbs) return H263MI_ERR_INVALID_ARGUMENT;
+    const FrameLayout L = make_layout(width, height);
+    const uint32_t n = L.mbw * L.mbh;
+    size_t used = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        MbRecord r = synth_mb_header(kind, stream_id, frame_idx, i);
+        r.coeff_index = (uint32_t)used;
+        for (int blk = 0; blk < 6; blk++) {
+            if (!((r.cbp >> blk) & 1)) continue;
+            if (coeffs) {
+                if (used >= coeff_capacity_blocks) return H263MI_ERR_INVALID_ARGUMENT;
+                synth_block_coeffs(kind, stream_id, frame_idx, i, blk, coeffs + used * 64);
+            }
+            used++;
+        }
+        mbs[i] = r;
+    }
+    if (n_coeff_blocks) *n_coeff_blocks = used;
+    return H263MI_OK;
+}
+
+int h263mi_synth_batch_device(const h263mi_backend_cfg *cfg, int kind, uint16_t width, uint16_t height,
+                              uint32_t n_streams, uint32_t first_stream_id, uint32_t frame_idx, h263mi_mb_record *d_mbs,
+                              int16_t *d_coeffs, size_t coeff_capacity_blocks, uint64_t *d_coeff_base,
+                              size_t *total_blocks)
+{
+    if (kind < 0 || kind > H263MI_SYNTH_P || !width || !height || !n_streams || !d_mbs || !d_coeffs || !d_coeff_base)
+        return H263MI_ERR_INVALID_ARGUMENT;
+    const int dev = cfg ? cfg->device_id : 0;
+    RC_TRY(check_device(dev));
+    DeviceGuard g(dev);
+    hipStream_t stream = cfg ? (hipStream_t)cfg->stream : nullptr;
+    const FrameLayout L = make_layout(width, height);
+    SynthArgs a{};
+    a.kind = kind;
+    a.n_streams = n_streams;
+    a.first_stream_id = first_stream_id;
+    a.frame_idx = frame_idx;
+    a.mbs_per_picture = L.mbw * L.mbh;
+    a.mbs = d_mbs;
+    a.coeffs = d_coeffs;
+    a.coeff_base = d_coeff_base;
+    TempBuf counts, totals;
+    HIP_TRY(hipMalloc(&counts.p, (size_t)n_streams * a.mbs_per_picture * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&totals.p, (size_t)n_streams * sizeof(uint32_t)));
+    a.counts = (uint32_t *)counts.p;
+    a.totals = (uint32_t *)totals.p;
+    HIP_TRY(launch_synth_headers(a, stream));
+    std::vector<uint32_t> h_totals(n_streams);
+    HIP_TRY(hipMemcpyAsync(h_totals.data(), totals.p, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<uint64_t> bases(n_streams);
+    uint64_t run = 0;
+    for (uint32_t p = 0; p < n_streams; p++) {
+        bases[p] = run;
+        run += h_totals[p];
+    }
+    if (total_blocks) *total_blocks = (size_t)run;
+    if (run > coeff_capacity_blocks) return H263MI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipMemcpyAsync(d_coeff_base, bases.data(), n_streams * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(launch_synth_coeffs(a, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return H263MI_OK;
+}
+
+}  // extern "C"

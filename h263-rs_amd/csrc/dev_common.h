@@ -1,0 +1,176 @@
+// dev_common.h -- types and helpers shared by the HIP kernels and their host launchers.
+//
+// Kernel bodies are written as per-phase inline functions taking explicit thread /
+// block indices (recon_kernel.inl, post_kernel.inl).  kernels.hip wraps them in
+// __global__ functions with __syncthreads() between phases.  tests/sim/ compiles the
+// same phase functions with g++ (ASan/UBSan) and runs the threads of a workgroup in a
+// loop, one phase at a time -- a logic checker for index math and edge handling, used
+// by the CPU test-suite only; it is not a product path.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/h263mi.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define H263_DEV __device__ __forceinline__
+#define H263_HD __host__ __device__ __forceinline__
+#else
+#define H263_DEV inline
+#define H263_HD inline
+// g++ build (tests/sim only): minimal stand-ins for the HIP vector types the phases use
+struct uint4 { uint32_t x, y, z, w; };
+struct float4 { float x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+#endif
+
+namespace h263mi {
+
+// ---------------------------------------------------------------------------
+// Frame layout in HBM.  One frame = Y plane, then Cb, then Cr, each PITCHED and
+// padded to whole macroblocks so kernels can write whole 8x8 blocks; only the
+// w x h (cw x ch) window is ever read back or used as reference samples.
+// ---------------------------------------------------------------------------
+struct FrameLayout {
+    uint32_t width, height;    // luma picture size
+    uint32_t cwidth, cheight;  // chroma picture size: ceil(w/2), ceil(h/2) (picture.rs:45-46)
+    uint32_t mbw, mbh;         // ceil(w/16), ceil(h/16) (state.rs:173-174)
+    uint32_t pitch_y, pitch_c; // row pitch in bytes (pitch_y = 2 * pitch_c, multiple of 128 / 64)
+    uint32_t rows_y, rows_c;   // allocated rows: mbh*16, mbh*8
+    uint32_t off_cb, off_cr;   // byte offset of the chroma planes inside a frame
+    uint32_t frame_bytes;      // bytes per frame incl. tail padding (multiple of 256)
+    uint32_t pad;
+};
+
+H263_HD FrameLayout make_layout(uint32_t w, uint32_t h)
+{
+    FrameLayout L;
+    L.width = w;
+    L.height = h;
+    L.cwidth = (w + 1) / 2;
+    L.cheight = (h + 1) / 2;
+    L.mbw = (w + 15) / 16;
+    L.mbh = (h + 15) / 16;
+    L.pitch_c = ((L.mbw * 8 + 63) / 64) * 64;
+    L.pitch_y = L.pitch_c * 2;
+    L.rows_y = L.mbh * 16;
+    L.rows_c = L.mbh * 8;
+    L.off_cb = L.pitch_y * L.rows_y;
+    L.off_cr = L.off_cb + L.pitch_c * L.rows_c;
+    // +256: unaligned 8/16-byte motion-compensation reads may run a few bytes past the last row
+    L.frame_bytes = ((L.off_cr + L.pitch_c * L.rows_c + 256 + 255) / 256) * 256;
+    L.pad = 0;
+    return L;
+}
+
+typedef h263mi_mb_record MbRecord;
+static_assert(sizeof(MbRecord) == 32, "record layout is part of the ABI");
+
+// status bits written by kernels into a device word, read back at sync time
+enum : uint32_t {
+    STATUS_INTER_WITHOUT_REFERENCE = 1u,   // gather.rs:149 Error::UncodedIFrameBlocks
+    STATUS_COEFF_INDEX_OUT_OF_RANGE = 2u,
+};
+
+// ---------------------------------------------------------------------------
+// reconstruction kernel arguments
+// ---------------------------------------------------------------------------
+struct ReconArgs {
+    FrameLayout L;
+    const MbRecord *mbs;         // n_pictures * mbs_per_picture records
+    const int16_t *coeffs;       // coefficient pool
+    const uint64_t *coeff_base;  // per picture base (blocks) or nullptr
+    const uint8_t *ref;          // reference frames (picture p at + p*frame_bytes); never null
+    uint8_t *cur;                // output frames
+    uint32_t *status;            // device status word
+    uint64_t coeff_pool_blocks;  // size of the pool, for the bounds check (0 = unchecked)
+    uint32_t n_pictures;
+    uint32_t mbs_per_picture;
+    uint32_t has_ref;            // 0: inter macroblocks are an error
+    uint32_t tiles_x, tiles_y;
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------
+// post kernel (deblock + BT.601) arguments
+// ---------------------------------------------------------------------------
+struct PostArgs {
+    FrameLayout L;
+    const uint8_t *frames;       // picture p at + p*frame_bytes
+    uint8_t *rgba;               // n_pictures * w*h*4, tightly packed, or nullptr
+    uint8_t *planes_out;         // n_pictures * (w*h + 2*cw*ch) tightly packed deblocked planes, or nullptr
+    uint32_t n_pictures;
+    uint32_t strength;           // 0 = no deblocking
+    uint32_t tiles_x, tiles_y;
+    uint32_t luma_only;          // standalone deblock() of a single plane
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------
+// small integer helpers
+// ---------------------------------------------------------------------------
+H263_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// types.rs:955-961 IntraDc::into_level
+H263_HD int intradc_level(uint32_t code) { return code == 0xFFu ? 1024 : (int)(code << 3); }
+
+// types.rs:653-658 / 661-663
+H263_HD bool mb_is_inter(uint32_t t) { return t == 0 || t == 1 || t == 2 || t == 5; }
+H263_HD bool mb_is_intra(uint32_t t) { return t == 3 || t == 4; }
+
+// types.rs:759-768 HalfPel::average_sum_of_mvs on the i16 sum of four vectors
+H263_HD int average_sum_of_mvs(int sum)
+{
+    int s = (int)(int16_t)sum;
+    int whole = (s >> 4) * 2;   // (s >> 4) << 1 in the reference; written without shifting a negative
+    int frac = s & 15;
+    return frac <= 2 ? whole : (frac >= 14 ? whole + 2 : whole + 1);
+}
+
+// rle.rs:130-133 dequantisation of one LEVEL (0 stays 0)
+H263_HD int dequant_level(int level, int quant)
+{
+    int a = level < 0 ? -level : level;
+    int m = quant * (2 * a + 1) - ((quant & 1) ? 0 : 1);
+    int v = level < 0 ? -m : m;
+    v = clampi(v, -2048, 2047);
+    return level == 0 ? 0 : v;
+}
+
+// per-byte (a + b + 1) >> 1 on 8 packed bytes: gather.rs:34-40 lerp, div_ceil(2)
+H263_HD uint64_t avg2_u8x8(uint64_t a, uint64_t b)
+{
+    return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f7f7f7f7full);
+}
+
+// per-byte (a + b + c + d + 2) >> 2 on 8 packed bytes: gather.rs:103-111
+H263_HD uint64_t avg4_u8x8(uint64_t a, uint64_t b, uint64_t c, uint64_t d)
+{
+    const uint64_t M = 0x00ff00ff00ff00ffull, R = 0x0002000200020002ull;
+    uint64_t e = (a & M) + (b & M) + (c & M) + (d & M) + R;
+    uint64_t o = ((a >> 8) & M) + ((b >> 8) & M) + ((c >> 8) & M) + ((d >> 8) & M) + R;
+    return ((e >> 2) & M) | (((o >> 2) & M) << 8);
+}
+
+H263_HD uint64_t load_u64_unaligned(const uint8_t *p)
+{
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+
+// idct.rs:39-48 BASIS_TABLE[freq][x] -- the reference's literals (not exact cosines).
+#define H263MI_BASIS_ROWS                                                                                          \
+    {0.70710677f, 0.70710677f, 0.70710677f, 0.70710677f, 0.70710677f, 0.70710677f, 0.70710677f, 0.70710677f},       \
+    {0.98078525f, 0.8314696f, 0.5555702f, 0.19509023f, -0.19509032f, -0.55557036f, -0.83146966f, -0.9807853f},      \
+    {0.9238795f, 0.38268343f, -0.38268352f, -0.9238796f, -0.9238795f, -0.38268313f, 0.3826836f, 0.92387956f},       \
+    {0.8314696f, -0.19509032f, -0.9807853f, -0.55557f, 0.55557007f, 0.98078525f, 0.19509007f, -0.8314698f},         \
+    {0.70710677f, -0.70710677f, -0.70710665f, 0.707107f, 0.70710677f, -0.70710725f, -0.70710653f, 0.7071068f},      \
+    {0.5555702f, -0.9807853f, 0.19509041f, 0.83146936f, -0.8314698f, -0.19508928f, 0.9807853f, -0.55557007f},       \
+    {0.38268343f, -0.9238795f, 0.92387974f, -0.3826839f, -0.38268384f, 0.9238793f, -0.92387974f, 0.3826839f},       \
+    {0.19509023f, -0.55557f, 0.83146936f, -0.9807852f, 0.98078525f, -0.83147013f, 0.55557114f, -0.19508967f}
+
+}  // namespace h263mi

@@ -1,0 +1,25 @@
+// kernels.h -- host-visible launchers of the gfx950 kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "dev_common.h"
+
+namespace h263mi {
+
+struct SynthArgs {
+    int kind;
+    uint32_t n_streams, first_stream_id, frame_idx, mbs_per_picture;
+    MbRecord *mbs;              // device, n_streams * mbs_per_picture
+    uint32_t *counts;           // device scratch, one per macroblock
+    uint32_t *totals;           // device, coded blocks per picture
+    int16_t *coeffs;            // device pool
+    const uint64_t *coeff_base; // device, per picture
+};
+
+hipError_t launch_recon(const ReconArgs &args, hipStream_t stream);
+hipError_t launch_post(const PostArgs &args, hipStream_t stream);
+hipError_t launch_synth_headers(const SynthArgs &args, hipStream_t stream);
+hipError_t launch_synth_coeffs(const SynthArgs &args, hipStream_t stream);
+
+}  // namespace h263mi

@@ -1,0 +1,395 @@
+"""ctypes binding of libh263mi.so (the C ABI of include/h263mi.h) for the tests and bench.py.
+
+Python here is plumbing only: every compute call goes through the C ABI into the gfx950
+kernels.  There is no fallback -- if the library or a GPU is missing, calls raise.
+
+The class and function names mirror the reference API (ruffle-rs/h263-rs):
+  H263State.decode_next_picture / get_last_picture / as_yuv   h263/src/decoder/state.rs
+  deblock(data, width, strength), QUANT_TO_STRENGTH           deblock/src/deblock.rs:5-8,305
+  yuv420_to_rgba(y, chroma_b, chroma_r, y_width)              yuv/src/bt601.rs:105
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libh263mi.so")
+
+OK = 0
+ERR_UNCODED_IFRAME_BLOCKS = -15
+ERR_UNIMPLEMENTED_DECODING = -17
+ERR_PICTURE_FORMAT_INVALID = -14
+ERR_INVALID_ARGUMENT = -100
+ERR_NO_DEVICE = -101
+ERR_NO_PICTURE = -104
+
+SORENSON_SPARK_BITSTREAM = 1
+USE_SCALABILITY_MODE = 2
+PICTURE_I, PICTURE_P, PICTURE_DISPOSABLE_P = 0, 1, 2
+SYNTH_I_DENSE, SYNTH_I_MIXED, SYNTH_P = 0, 1, 2
+
+MB_RECORD_DTYPE = np.dtype([
+    ("mb_type", "u1"), ("quant", "u1"), ("cbp", "u1"), ("kill", "u1"),
+    ("mv", "<i2", (4, 2)), ("intradc", "u1", (6,)), ("reserved", "u1", (2,)),
+    ("coeff_index", "<u4"),
+])
+
+EXPORTS = [
+    "h263mi_strerror", "h263mi_abi_version",
+    "h263mi_state_new", "h263mi_state_free", "h263mi_state_is_sorenson", "h263mi_state_reset",
+    "h263mi_state_cleanup_buffers", "h263mi_submit_picture", "h263mi_decode_next_picture",
+    "h263mi_get_last_picture", "h263mi_get_reference_picture", "h263mi_copy_yuv", "h263mi_render_rgba",
+    "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
+    "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
+    "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
+    "h263mi_batch_timing_begin", "h263mi_batch_timing_end",
+    "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
+    "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
+    "h263mi_synth_picture_host", "h263mi_synth_batch_device",
+]
+
+
+class H263Error(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().h263mi_strerror(code).decode() if _lib is not None else str(code)
+        super().__init__("%s: %s (%d)" % (what, msg, code))
+
+
+class PictureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("picture_type", C.c_uint8), ("pquant", C.c_uint8),
+                ("use_deblocker", C.c_uint8), ("reserved0", C.c_uint8), ("temporal_reference", C.c_uint16),
+                ("reserved1", C.c_uint16)]
+
+
+class BackendCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("chroma_width", C.c_uint16),
+                ("chroma_height", C.c_uint16), ("temporal_reference", C.c_uint16), ("picture_type", C.c_uint8),
+                ("pquant", C.c_uint8), ("use_deblocker", C.c_uint8), ("reserved", C.c_uint8 * 3),
+                ("dev_y", C.c_void_p), ("dev_cb", C.c_void_p), ("dev_cr", C.c_void_p),
+                ("dev_pitch_y", C.c_uint32), ("dev_pitch_c", C.c_uint32)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("recon_ms", C.c_double), ("recon_launches", C.c_uint32), ("pad0", C.c_uint32),
+                ("post_ms", C.c_double), ("post_launches", C.c_uint32), ("pad1", C.c_uint32)]
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the shared library (h263-rs_amd/Makefile)."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library; fails loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libh263mi.so is missing: run `make -C h263-rs_amd` (hipcc, gfx950). "
+                               "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, sz, u8, u16, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint16, C.c_uint32, C.c_int
+        L.h263mi_strerror.restype = C.c_char_p
+        L.h263mi_strerror.argtypes = [i32]
+        L.h263mi_state_new.argtypes = [u32, C.POINTER(BackendCfg), C.POINTER(vp)]
+        L.h263mi_state_free.argtypes = [vp]
+        L.h263mi_state_free.restype = None
+        L.h263mi_state_is_sorenson.argtypes = [vp]
+        L.h263mi_state_reset.argtypes = [vp]
+        L.h263mi_state_cleanup_buffers.argtypes = [vp]
+        L.h263mi_submit_picture.argtypes = [vp, C.POINTER(PictureDesc), vp, sz, vp, sz]
+        L.h263mi_decode_next_picture.argtypes = [vp, vp, sz, C.POINTER(sz)]
+        L.h263mi_get_last_picture.argtypes = [vp, C.POINTER(FrameView)]
+        L.h263mi_get_reference_picture.argtypes = [vp, C.POINTER(FrameView)]
+        L.h263mi_copy_yuv.argtypes = [vp, vp, vp, vp]
+        L.h263mi_render_rgba.argtypes = [vp, u8, vp]
+        L.h263mi_deblock.argtypes = [vp, sz, sz, u8, vp]
+        L.h263mi_bt601_yuv420_to_rgba.argtypes = [vp, sz, vp, vp, sz, sz, vp]
+        L.h263mi_batch_create.argtypes = [u32, u16, u16, C.POINTER(BackendCfg), C.POINTER(vp)]
+        L.h263mi_batch_destroy.argtypes = [vp]
+        L.h263mi_batch_destroy.restype = None
+        L.h263mi_batch_mbs_per_picture.argtypes = [vp]
+        L.h263mi_batch_mbs_per_picture.restype = u32
+        L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
+        L.h263mi_batch_render_rgba.argtypes = [vp, u8, vp, vp]
+        L.h263mi_batch_sync.argtypes = [vp]
+        L.h263mi_batch_reset.argtypes = [vp]
+        L.h263mi_batch_copy_yuv.argtypes = [vp, u32, vp, vp, vp]
+        L.h263mi_batch_timing_begin.argtypes = [vp]
+        L.h263mi_batch_timing_end.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.h263mi_device_count.argtypes = [C.POINTER(i32)]
+        L.h263mi_device_malloc.argtypes = [i32, sz, C.POINTER(vp)]
+        L.h263mi_device_free.argtypes = [i32, vp]
+        L.h263mi_device_memcpy_h2d.argtypes = [i32, vp, vp, sz]
+        L.h263mi_device_memcpy_d2h.argtypes = [i32, vp, vp, sz]
+        L.h263mi_device_synchronize.argtypes = [i32]
+        L.h263mi_synth_picture_host.argtypes = [i32, u16, u16, u32, u32, vp, vp, sz, C.POINTER(sz)]
+        L.h263mi_synth_batch_device.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, vp, vp, sz, vp,
+                                                C.POINTER(sz)]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != OK:
+        raise H263Error(rc, what)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().h263mi_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+QUANT_TO_STRENGTH = None
+
+
+def quant_to_strength():
+    """deblock::QUANT_TO_STRENGTH (deblock.rs:5-8)."""
+    return np.array((C.c_uint8 * 32).in_dll(lib(), "h263mi_quant_to_strength"), dtype=np.uint8)
+
+
+def deblock(data, width, strength):
+    """deblock::deblock(data, width, strength) -> Vec<u8> (deblock.rs:305), on the GPU."""
+    data = np.ascontiguousarray(data, dtype=np.uint8).ravel()
+    out = np.empty_like(data)
+    _check(lib().h263mi_deblock(_p(data), data.size, width, strength, _p(out)), "deblock")
+    return out
+
+
+def yuv420_to_rgba(y, chroma_b, chroma_r, y_width):
+    """yuv::bt601::yuv420_to_rgba(y, chroma_b, chroma_r, y_width) -> Vec<u8> (bt601.rs:105), on the GPU."""
+    y = np.ascontiguousarray(y, dtype=np.uint8).ravel()
+    cb = np.ascontiguousarray(chroma_b, dtype=np.uint8).ravel()
+    cr = np.ascontiguousarray(chroma_r, dtype=np.uint8).ravel()
+    if cb.size != cr.size:
+        raise H263Error(ERR_INVALID_ARGUMENT, "yuv420_to_rgba")
+    out = np.empty(y.size * 4, dtype=np.uint8)
+    _check(lib().h263mi_bt601_yuv420_to_rgba(_p(y), y.size, _p(cb), _p(cr), cb.size, y_width, _p(out)),
+           "yuv420_to_rgba")
+    return out
+
+
+class DecodedPicture:
+    """Host-side copy of DecodedPicture (h263/src/decoder/picture.rs:8-58)."""
+
+    def __init__(self, view, y, cb, cr):
+        self.width, self.height = view.width, view.height
+        self.chroma_width, self.chroma_height = view.chroma_width, view.chroma_height
+        self.temporal_reference = view.temporal_reference
+        self.picture_type = view.picture_type
+        self.pquant = view.pquant
+        self.use_deblocker = view.use_deblocker
+        self._yuv = (y, cb, cr)
+
+    def luma_samples_per_row(self):
+        return self.width
+
+    def chroma_samples_per_row(self):
+        return self.chroma_width
+
+    def as_luma(self):
+        return self._yuv[0]
+
+    def as_chroma_b(self):
+        return self._yuv[1]
+
+    def as_chroma_r(self):
+        return self._yuv[2]
+
+    def as_yuv(self):
+        return self._yuv
+
+
+class H263State:
+    """H263State (h263/src/decoder/state.rs:16-490) over the C ABI."""
+
+    def __init__(self, decoder_options=SORENSON_SPARK_BITSTREAM, device_id=0, stream=None):
+        self._h = C.c_void_p()
+        self._cfg = BackendCfg(device_id, 0, stream)
+        _check(lib().h263mi_state_new(decoder_options, C.byref(self._cfg), C.byref(self._h)), "H263State::new")
+
+    def close(self):
+        if self._h:
+            lib().h263mi_state_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_sorenson(self):
+        return bool(lib().h263mi_state_is_sorenson(self._h))
+
+    def reset(self):
+        _check(lib().h263mi_state_reset(self._h), "reset")
+
+    def cleanup_buffers(self):
+        _check(lib().h263mi_state_cleanup_buffers(self._h), "cleanup_buffers")
+
+    def submit_picture(self, width, height, mbs, coeffs, picture_type=PICTURE_I, temporal_reference=0, pquant=1,
+                       use_deblocker=0):
+        """Record-level decode_next_picture (state.rs:421-483); raises H263Error on failure."""
+        mbs = np.ascontiguousarray(mbs, dtype=MB_RECORD_DTYPE)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int16).reshape(-1, 64)
+        d = PictureDesc(width, height, picture_type, pquant, use_deblocker, 0, temporal_reference, 0)
+        _check(lib().h263mi_submit_picture(self._h, C.byref(d), _p(mbs) if mbs.size else None, mbs.size,
+                                           _p(coeffs) if coeffs.size else None, coeffs.shape[0]), "submit_picture")
+
+    def decode_next_picture(self, data):
+        data = np.frombuffer(bytes(data), dtype=np.uint8)
+        used = C.c_size_t(0)
+        _check(lib().h263mi_decode_next_picture(self._h, _p(data), data.size, C.byref(used)), "decode_next_picture")
+        return used.value
+
+    def _view(self, fn, what):
+        v = FrameView()
+        rc = fn(self._h, C.byref(v))
+        if rc == ERR_NO_PICTURE:
+            return None
+        _check(rc, what)
+        return v
+
+    def get_last_picture(self):
+        """Option<&DecodedPicture> (state.rs:61-67): None before the first picture."""
+        v = self._view(lib().h263mi_get_last_picture, "get_last_picture")
+        if v is None:
+            return None
+        y = np.empty(v.width * v.height, np.uint8)
+        cb = np.empty(v.chroma_width * v.chroma_height, np.uint8)
+        cr = np.empty_like(cb)
+        _check(lib().h263mi_copy_yuv(self._h, _p(y), _p(cb), _p(cr)), "as_yuv")
+        return DecodedPicture(v, y, cb, cr)
+
+    def has_reference_picture(self):
+        return self._view(lib().h263mi_get_reference_picture, "get_reference_picture") is not None
+
+    def render_rgba(self, strength=0):
+        v = self._view(lib().h263mi_get_last_picture, "get_last_picture")
+        if v is None:
+            raise H263Error(ERR_NO_PICTURE, "render_rgba")
+        out = np.empty(v.width * v.height * 4, np.uint8)
+        _check(lib().h263mi_render_rgba(self._h, strength, _p(out)), "render_rgba")
+        return out
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes, device_id=0):
+        self.device_id, self.nbytes = device_id, nbytes
+        self.ptr = C.c_void_p()
+        _check(lib().h263mi_device_malloc(device_id, nbytes, C.byref(self.ptr)), "device_malloc")
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        _check(lib().h263mi_device_memcpy_h2d(self.device_id, C.c_void_p(self.ptr.value + offset), _p(arr),
+                                              arr.nbytes), "h2d")
+
+    def download(self, nbytes=None, offset=0, dtype=np.uint8):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(nbytes, np.uint8)
+        _check(lib().h263mi_device_memcpy_d2h(self.device_id, _p(out), C.c_void_p(self.ptr.value + offset), nbytes),
+               "d2h")
+        return out.view(dtype)
+
+    def at(self, offset):
+        return C.c_void_p(self.ptr.value + offset)
+
+    def free(self):
+        if self.ptr:
+            lib().h263mi_device_free(self.device_id, self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Batch:
+    """N independent streams advancing in lock step on one GPU (h263mi_batch_*)."""
+
+    def __init__(self, n_streams, width, height, device_id=0, stream=None):
+        self.n, self.width, self.height, self.device_id = n_streams, width, height, device_id
+        self._cfg = BackendCfg(device_id, 0, stream)
+        self._h = C.c_void_p()
+        _check(lib().h263mi_batch_create(n_streams, width, height, C.byref(self._cfg), C.byref(self._h)),
+               "batch_create")
+        self.mbs_per_picture = lib().h263mi_batch_mbs_per_picture(self._h)
+
+    def close(self):
+        if self._h:
+            lib().h263mi_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, picture_type, d_mbs, d_coeffs, d_coeff_base=None):
+        _check(lib().h263mi_batch_submit(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base), "batch_submit")
+
+    def render_rgba(self, strength, d_rgba, d_deblocked=None):
+        _check(lib().h263mi_batch_render_rgba(self._h, strength, d_rgba, d_deblocked), "batch_render_rgba")
+
+    def sync(self):
+        _check(lib().h263mi_batch_sync(self._h), "batch_sync")
+
+    def reset(self):
+        _check(lib().h263mi_batch_reset(self._h), "batch_reset")
+
+    def copy_yuv(self, stream):
+        w, h = self.width, self.height
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        y, cb, cr = np.empty(w * h, np.uint8), np.empty(cw * ch, np.uint8), np.empty(cw * ch, np.uint8)
+        _check(lib().h263mi_batch_copy_yuv(self._h, stream, _p(y), _p(cb), _p(cr)), "batch_copy_yuv")
+        return y, cb, cr
+
+    def timing_begin(self):
+        _check(lib().h263mi_batch_timing_begin(self._h), "timing_begin")
+
+    def timing_end(self):
+        t = KernelTimes()
+        _check(lib().h263mi_batch_timing_end(self._h, C.byref(t)), "timing_end")
+        return t
+
+
+def synth_picture_host(kind, width, height, stream_id, frame_idx):
+    total = ((width + 15) // 16) * ((height + 15) // 16)
+    mbs = np.zeros(total, MB_RECORD_DTYPE)
+    coeffs = np.zeros((total * 6, 64), np.int16)
+    n = C.c_size_t(0)
+    _check(lib().h263mi_synth_picture_host(kind, width, height, stream_id, frame_idx, _p(mbs), _p(coeffs), total * 6,
+                                           C.byref(n)), "synth_picture_host")
+    return mbs, coeffs[:n.value].copy()
+
+
+def synth_batch_device(kind, width, height, n_streams, first_stream_id, frame_idx, d_mbs, d_coeffs, capacity_blocks,
+                       d_coeff_base, device_id=0, stream=None):
+    cfg = BackendCfg(device_id, 0, stream)
+    total = C.c_size_t(0)
+    _check(lib().h263mi_synth_batch_device(C.byref(cfg), kind, width, height, n_streams, first_stream_id, frame_idx,
+                                           d_mbs, d_coeffs, capacity_blocks, d_coeff_base, C.byref(total)),
+           "synth_batch_device")
+    return total.value

@@ -1,0 +1,279 @@
+/*
+ * h263mi.h -- C ABI of the MI355X-native macroblock back-end for h263-rs.
+ *
+ * This is the drop-in boundary: every entry point replaces one interface of the
+ * reference (ruffle-rs/h263-rs, cited as file:line relative to the reference root).
+ * The serial bitstream/VLC parse stays on the host; per picture it emits a flat array
+ * of macroblock records which crosses this ABI into hand-written HIP kernels (gfx950)
+ * that do dequantisation + 8x8 inverse DCT, half-pel motion compensation, residual add
+ * with clipping, the deblocking post-filter and the BT.601 YUV->RGBA conversion.
+ *
+ * All functions return H263MI_OK (0) or a negative error code.  There is NO CPU
+ * fallback: without a HIP device every compute entry point returns
+ * H263MI_ERR_NO_DEVICE.
+ *
+ * Threading (mirrors `&mut self` on H263State, state.rs:16-38): one h263mi_state /
+ * h263mi_batch per stream (or per batch of streams), not thread-safe per object;
+ * distinct objects may be driven from different host threads.
+ */
+#ifndef H263MI_H
+#define H263MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H263MI_ABI_VERSION 1
+
+/* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
+#define H263MI_OK                                  0
+#define H263MI_ERR_INTERNAL_DECODER_ERROR        (-1)
+#define H263MI_ERR_MIDDLE_OF_BITSTREAM           (-2)
+#define H263MI_ERR_INVALID_MACROBLOCK_HEADER     (-3)
+#define H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS (-4)
+#define H263MI_ERR_INVALID_INTRA_DC              (-5)
+#define H263MI_ERR_INVALID_SHORT_COEFFICIENT     (-6)
+#define H263MI_ERR_INVALID_LONG_COEFFICIENT      (-7)
+#define H263MI_ERR_INVALID_MVD                   (-8)
+#define H263MI_ERR_INVALID_PTYPE                 (-9)
+#define H263MI_ERR_INVALID_PLUS_PTYPE            (-10)
+#define H263MI_ERR_INVALID_GOB_HEADER            (-11)
+#define H263MI_ERR_INVALID_BITSTREAM             (-12)
+#define H263MI_ERR_PICTURE_FORMAT_MISSING        (-13)
+#define H263MI_ERR_PICTURE_FORMAT_INVALID        (-14)
+#define H263MI_ERR_UNCODED_IFRAME_BLOCKS         (-15)  /* gather.rs:149, state.rs:211-213 */
+#define H263MI_ERR_UNHANDLED_IO_ERROR            (-16)  /* incl. UnexpectedEof */
+#define H263MI_ERR_UNIMPLEMENTED_DECODING        (-17)
+/* back-end errors (no counterpart in the reference) */
+#define H263MI_ERR_INVALID_ARGUMENT              (-100)
+#define H263MI_ERR_NO_DEVICE                     (-101)
+#define H263MI_ERR_HIP                           (-102)
+#define H263MI_ERR_OUT_OF_MEMORY                 (-103)
+#define H263MI_ERR_NO_PICTURE                    (-104) /* get_last_picture() == None, state.rs:61-67 */
+
+const char *h263mi_strerror(int code);          /* messages of error.rs:7-57 */
+int  h263mi_abi_version(void);
+
+/* ---- decoder options: h263/src/decoder/types.rs:3-17 (DecoderOption bitflags) ---- */
+#define H263MI_SORENSON_SPARK_BITSTREAM 0x1u
+#define H263MI_USE_SCALABILITY_MODE     0x2u
+
+/* ---- macroblock types: h263/src/types.rs:631-649 (MacroblockType) ---- */
+#define H263MI_MB_INTER     0
+#define H263MI_MB_INTER_Q   1
+#define H263MI_MB_INTER4V   2
+#define H263MI_MB_INTRA     3
+#define H263MI_MB_INTRA_Q   4
+#define H263MI_MB_INTER4V_Q 5
+
+/*
+ * One record per macroblock, raster order (state.rs:199-202).  It carries exactly the
+ * state the reference holds at its cut line (state.rs:429-438) before it calls
+ * gather() + idct_channel():
+ *
+ *   mb_type      MacroblockType; an uncoded or padded macroblock is Inter with cbp 0 and
+ *                mv 0 (state.rs:207-216, 421-427).
+ *   quant        quantiser in force, 1..31, after the DQUANT clamp (state.rs:226-227).
+ *   cbp          bit b set <=> block b (Y0 Y1 Y2 Y3 Cb Cr) carries TCOEFs
+ *                (CodedBlockPattern, types.rs:683-687).
+ *   kill         bit b set <=> a run of block b walked past zigzag 63: the block
+ *                contributes nothing, its INTRADC included (rle.rs:125-127).
+ *   mv           the four absolute half-pel luma motion vectors {x, y} after prediction
+ *                (state.rs:238-284); one-vector macroblocks replicate mv[0].
+ *   intradc      raw INTRADC code of each block for intra macroblocks (types.rs:923-961:
+ *                level = code << 3, 0xFF -> 1024; 0 and 128 never occur), else 0.
+ *   coeff_index  index, in 64-coefficient blocks, of this macroblock's first coded
+ *                block in the coefficient array; its coded blocks follow each other in
+ *                block order.
+ *
+ * Coefficient array: int16_t[64] per coded block, RASTER order (x + 8*y) -- i.e. already
+ * run-length expanded and de-zigzagged (rle.rs:6-71, 122-136) -- holding the quantised
+ * LEVEL (0 = absent).  Dequantisation (rle.rs:130-133), the Zero/Dc/Horiz/Vert/Full
+ * classification (rle.rs:94-109, 138-170) and everything after it run on the GPU.
+ * For intra blocks coefficient 0 is ignored (the DC comes from `intradc`).
+ * Contract (as in the reference, rle.rs:130): quant * (2*|LEVEL| + 1) <= 32767.
+ */
+typedef struct h263mi_mb_record {
+    uint8_t  mb_type;
+    uint8_t  quant;
+    uint8_t  cbp;
+    uint8_t  kill;
+    int16_t  mv[4][2];
+    uint8_t  intradc[6];
+    uint8_t  reserved[2];
+    uint32_t coeff_index;
+} h263mi_mb_record;                                  /* 32 bytes */
+
+/* Picture-level fields the back-end needs from `Picture` (types.rs:20-90). */
+#define H263MI_PICTURE_I 0   /* PictureTypeCode::IFrame: clears the reference (state.rs:464-470) */
+#define H263MI_PICTURE_P 1   /* PFrame */
+#define H263MI_PICTURE_DISPOSABLE_P 2 /* does not become the reference (state.rs:474-480) */
+typedef struct h263mi_picture_desc {
+    uint16_t width, height;        /* SourceFormat::into_width_and_height (state.rs:169-171) */
+    uint8_t  picture_type;
+    uint8_t  pquant;               /* Picture::quantizer */
+    uint8_t  use_deblocker;        /* PictureOption::USE_DEBLOCKER (types.rs:213-216), advisory */
+    uint8_t  reserved0;
+    uint16_t temporal_reference;   /* Picture::temporal_reference: key of the reference store */
+    uint16_t reserved1;
+} h263mi_picture_desc;                               /* 12 bytes */
+
+/* Where the back-end runs.  `stream` is a hipStream_t (NULL = the device's null stream). */
+typedef struct h263mi_backend_cfg {
+    int32_t  device_id;
+    uint32_t flags;
+    void    *stream;
+} h263mi_backend_cfg;
+
+/* ======================================================================= */
+/* H263State  (h263/src/decoder/state.rs)                                   */
+/* ======================================================================= */
+typedef struct h263mi_state h263mi_state;
+
+/* H263State::new(decoder_options)  state.rs:42-50.  cfg may be NULL (device 0, null stream). */
+int  h263mi_state_new(uint32_t decoder_options, const h263mi_backend_cfg *cfg, h263mi_state **out);
+void h263mi_state_free(h263mi_state *s);
+/* H263State::is_sorenson  state.rs:53-56 */
+int  h263mi_state_is_sorenson(const h263mi_state *s);
+/* Seeking rule of state.rs:134-137: discard all decoder state. */
+int  h263mi_state_reset(h263mi_state *s);
+/* H263State::cleanup_buffers  state.rs:81-98 (drops every picture but last/reference). */
+int  h263mi_state_cleanup_buffers(h263mi_state *s);
+
+/*
+ * The record-level form of H263State::decode_next_picture (state.rs:138-489): the caller
+ * has run the serial parse (state.rs:193-417) and hands over the macroblock records; this
+ * call performs state.rs:421-483 -- pad missing macroblocks as Inter/mv 0, gather(),
+ * idct_channel() x3 on the GPU, then the reference bookkeeping.  `mbs` and `coeffs` are
+ * HOST pointers; n_mbs <= ceil(w/16)*ceil(h/16).  On error the state is unchanged
+ * (state.rs:142, 464-487).  Returns H263MI_ERR_UNCODED_IFRAME_BLOCKS when an inter
+ * macroblock has no reference picture (gather.rs:149).
+ */
+int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc,
+                          const h263mi_mb_record *mbs, size_t n_mbs,
+                          const int16_t *coeffs, size_t n_coeff_blocks);
+
+/*
+ * H263State::decode_next_picture(reader)  state.rs:138-141, over a byte buffer holding
+ * one coded picture (Ruffle hands one FLV video tag per reader).  `*consumed` receives the
+ * bytes used.  Needs the host bitstream parser.
+ */
+int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len, size_t *consumed);
+
+/* DecodedPicture accessors (picture.rs:61-142) of get_last_picture() (state.rs:61-67). */
+typedef struct h263mi_frame_view {
+    uint16_t width, height;              /* luma_samples_per_row, rows */
+    uint16_t chroma_width, chroma_height;/* chroma_samples_per_row (picture.rs:45-46) */
+    uint16_t temporal_reference;
+    uint8_t  picture_type;
+    uint8_t  pquant;
+    uint8_t  use_deblocker;
+    uint8_t  reserved[3];
+    const uint8_t *dev_y, *dev_cb, *dev_cr; /* DEVICE pointers, valid until the next decode */
+    uint32_t dev_pitch_y, dev_pitch_c;      /* device row pitches in bytes */
+} h263mi_frame_view;
+int h263mi_get_last_picture(const h263mi_state *s, h263mi_frame_view *out);
+/* get_reference_picture (state.rs:72-78): mirrors the reference, which returns the LAST
+ * picture whenever a reference exists. */
+int h263mi_get_reference_picture(const h263mi_state *s, h263mi_frame_view *out);
+/* DecodedPicture::as_yuv (picture.rs:140-142): tightly packed planes (stride = width),
+ * w*h, cw*ch, cw*ch bytes, copied to HOST memory. */
+int h263mi_copy_yuv(const h263mi_state *s, uint8_t *y, uint8_t *cb, uint8_t *cr);
+/*
+ * What the consumer does after decoding: optional deblock() of each plane
+ * with `strength` (0 = no deblocking, else 1..12) followed by yuv420_to_rgba(), fused on
+ * the device for the last picture; w*h*4 bytes to HOST memory.  The reference planes are
+ * not modified (post-filter, deblock.rs:1-2).
+ */
+int h263mi_render_rgba(const h263mi_state *s, uint8_t strength, uint8_t *rgba);
+
+/* ======================================================================= */
+/* deblock crate  (deblock/src/deblock.rs)                                  */
+/* ======================================================================= */
+/* pub const QUANT_TO_STRENGTH: [u8; 32]  deblock.rs:5-8 */
+extern const uint8_t h263mi_quant_to_strength[32];
+/* pub fn deblock(data, width, strength) -> Vec<u8>  deblock.rs:305-315.  HOST buffers,
+ * `out` holds `len` bytes; len % width == 0, 1 <= strength <= 12. */
+int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out);
+
+/* ======================================================================= */
+/* yuv crate  (yuv/src/bt601.rs)                                            */
+/* ======================================================================= */
+/* pub fn yuv420_to_rgba(y, chroma_b, chroma_r, y_width) -> Vec<u8>  bt601.rs:105-196.
+ * HOST buffers; rgba_out holds 4*y_len bytes.  Preconditions of bt601.rs:100-104 are
+ * checked and reported as H263MI_ERR_INVALID_ARGUMENT. */
+int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len,
+                                const uint8_t *chroma_b, const uint8_t *chroma_r, size_t c_len,
+                                size_t y_width, uint8_t *rgba_out);
+
+/* ======================================================================= */
+/* Batch of independent streams on one GPU (no counterpart in the reference:*/
+/* it is the data-parallel form of N H263States advancing in lock step).    */
+/* ======================================================================= */
+typedef struct h263mi_batch h263mi_batch;
+
+int  h263mi_batch_create(uint32_t n_streams, uint16_t width, uint16_t height,
+                         const h263mi_backend_cfg *cfg, h263mi_batch **out);
+void h263mi_batch_destroy(h263mi_batch *b);
+uint32_t h263mi_batch_mbs_per_picture(const h263mi_batch *b);
+/*
+ * One picture per stream.  DEVICE pointers: d_mbs holds n_streams * mbs_per_picture
+ * records (stream s at s * mbs_per_picture, all macroblocks present); d_coeffs is the
+ * coefficient pool; d_coeff_base[s] (may be NULL = all 0) is the block index in the pool
+ * that stream s's coeff_index values are relative to.  Asynchronous on the batch stream.
+ * picture_type as in h263mi_picture_desc.  An inter macroblock without a reference is
+ * detected on the device and reported by the next h263mi_batch_sync().
+ */
+int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
+                        const h263mi_mb_record *d_mbs, const int16_t *d_coeffs,
+                        const uint64_t *d_coeff_base);
+/* deblock (strength 0 = off) + BT.601 of every stream's last picture into d_rgba
+ * (DEVICE, n_streams * w*h*4 bytes, stream-major); d_deblocked (DEVICE, may be NULL)
+ * additionally receives the filtered planes, n_streams * (w*h + 2*cw*ch) bytes as
+ * Y,Cb,Cr per stream, tightly packed. */
+int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
+int h263mi_batch_sync(h263mi_batch *b);
+int h263mi_batch_reset(h263mi_batch *b);
+/* as_yuv of stream `stream`'s last picture -> HOST, tightly packed. */
+int h263mi_batch_copy_yuv(h263mi_batch *b, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr);
+
+/* Per-kernel device time between begin/end, measured with hipEvents on the batch stream. */
+typedef struct h263mi_kernel_times {
+    double   recon_ms;  uint32_t recon_launches;  uint32_t pad0;
+    double   post_ms;   uint32_t post_launches;   uint32_t pad1;
+} h263mi_kernel_times;
+int h263mi_batch_timing_begin(h263mi_batch *b);
+int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out);
+
+/* ======================================================================= */
+/* Device memory + synthetic macroblock records (bench / test support)      */
+/* ======================================================================= */
+int h263mi_device_count(int *count);
+int h263mi_device_malloc(int device_id, size_t bytes, void **out);
+int h263mi_device_free(int device_id, void *p);
+int h263mi_device_memcpy_h2d(int device_id, void *dst, const void *src, size_t bytes);
+int h263mi_device_memcpy_d2h(int device_id, void *dst, const void *src, size_t bytes);
+int h263mi_device_synchronize(int device_id);
+
+#define H263MI_SYNTH_I_DENSE 0  /* BASELINE config 2 "dense": every block Full */
+#define H263MI_SYNTH_I_MIXED 1  /* config 2 "mixed": Dc / Horiz / Vert / Full-dense / Full-sparse */
+#define H263MI_SYNTH_P       2  /* config 3: half-pel MVs in [-32,31], 25 % coded blocks, quant 10 */
+/* Counter-based splitmix64 records; host and device versions are bit-identical. */
+int h263mi_synth_picture_host(int kind, uint16_t width, uint16_t height,
+                              uint32_t stream_id, uint32_t frame_idx,
+                              h263mi_mb_record *mbs, int16_t *coeffs,
+                              size_t coeff_capacity_blocks, size_t *n_coeff_blocks);
+/* n_streams pictures (stream ids first_stream_id ..) straight into DEVICE memory.
+ * d_coeff_base receives each picture's base (blocks) in d_coeffs; *total_blocks the pool use. */
+int h263mi_synth_batch_device(const h263mi_backend_cfg *cfg, int kind, uint16_t width, uint16_t height,
+                              uint32_t n_streams, uint32_t first_stream_id, uint32_t frame_idx,
+                              h263mi_mb_record *d_mbs, int16_t *d_coeffs, size_t coeff_capacity_blocks,
+                              uint64_t *d_coeff_base, size_t *total_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H263MI_H */

@@ -70,7 +70,7 @@ void orc_lerp_parameters(int16_t hp, int16_t *delta, int *interp)
 /* types.rs:759-768  HalfPel::average_sum_of_mvs */
 int16_t orc_average_sum_of_mvs(int16_t sum)
 {
-    int16_t whole = (int16_t)((sum >> 4) << 1); /* arithmetic shift on i16 */
+    int16_t whole = (int16_t)((sum >> 4) * 2); /* (self.0 >> 4) << 1, arithmetic shift on i16 */
     int frac = sum & 0x0F;
     if (frac <= 2) return whole;
     if (frac >= 14) return (int16_t)(whole + 2);

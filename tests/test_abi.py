@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/h263mi.h declares, shares its record layout with the oracle, and -- with no GPU in the
+container -- fails loudly instead of falling back to a CPU path.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import h263mi
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not os.path.exists("/dev/kfd")
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "h263mi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(h263mi_[a-z0-9_]+)\s*\(", src))
+    names |= set(re.findall(r"extern const uint8_t (h263mi_[a-z0-9_]+)\[", src))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = h263mi.lib()
+    declared = header_symbols()
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(L, name), "include/h263mi.h declares %s but libh263mi.so does not export it" % name
+    assert declared == set(h263mi.EXPORTS), declared ^ set(h263mi.EXPORTS)
+    assert L.h263mi_abi_version() == 1
+
+
+def test_record_layout_matches_header_and_oracle():
+    assert h263mi.MB_RECORD_DTYPE == orc.MB_RECORD_DTYPE
+    assert h263mi.MB_RECORD_DTYPE.itemsize == 32
+    assert C.sizeof(h263mi.PictureDesc) == 12
+    offs = {n: h263mi.MB_RECORD_DTYPE.fields[n][1] for n in h263mi.MB_RECORD_DTYPE.names}
+    assert offs == {"mb_type": 0, "quant": 1, "cbp": 2, "kill": 3, "mv": 4, "intradc": 20, "reserved": 26,
+                    "coeff_index": 28}
+
+
+def test_tables_and_messages():
+    assert h263mi.quant_to_strength().tolist() == orc.quant_to_strength().tolist()
+    L = h263mi.lib()
+    assert b"uncoded iframe blocks" in L.h263mi_strerror(h263mi.ERR_UNCODED_IFRAME_BLOCKS)
+    assert b"no CPU fallback" in L.h263mi_strerror(h263mi.ERR_NO_DEVICE)
+
+
+def test_argument_validation_needs_no_device():
+    # preconditions of deblock.rs:30,306 and bt601.rs:100-104 are checked before any device work
+    buf = np.zeros(16, np.uint8)
+    out = np.zeros(64, np.uint8)
+    L = h263mi.lib()
+    assert L.h263mi_deblock(buf.ctypes.data, 16, 5, 3, out.ctypes.data) == h263mi.ERR_INVALID_ARGUMENT   # 16 % 5
+    assert L.h263mi_deblock(buf.ctypes.data, 16, 4, 0, out.ctypes.data) == h263mi.ERR_INVALID_ARGUMENT   # strength
+    assert L.h263mi_deblock(buf.ctypes.data, 16, 4, 13, out.ctypes.data) == h263mi.ERR_INVALID_ARGUMENT
+    assert L.h263mi_bt601_yuv420_to_rgba(None, 0, None, None, 0, 0, None) == h263mi.OK                   # empty picture
+    assert L.h263mi_bt601_yuv420_to_rgba(buf.ctypes.data, 16, buf.ctypes.data, buf.ctypes.data, 3, 4,
+                                         out.ctypes.data) == h263mi.ERR_INVALID_ARGUMENT                 # chroma size
+
+
+def test_host_synth_matches_sim_generator():
+    import simlib
+    for kind in (h263mi.SYNTH_I_DENSE, h263mi.SYNTH_I_MIXED, h263mi.SYNTH_P):
+        a_m, a_c = h263mi.synth_picture_host(kind, 64, 48, 5, 2)
+        b_m, b_c = simlib.synth_picture(kind, 64, 48, 5, 2)
+        assert a_m.tobytes() == b_m.tobytes() and a_c.tobytes() == b_c.tobytes()
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful where no GPU exists")
+def test_no_gpu_fails_loudly_and_never_falls_back():
+    assert h263mi.device_count() == 0
+    with pytest.raises(h263mi.H263Error) as e:
+        h263mi.H263State()
+    assert e.value.code == h263mi.ERR_NO_DEVICE
+    with pytest.raises(h263mi.H263Error) as e:
+        h263mi.deblock(np.zeros(64, np.uint8), 8, 4)
+    assert e.value.code == h263mi.ERR_NO_DEVICE
+    with pytest.raises(h263mi.H263Error) as e:
+        h263mi.yuv420_to_rgba(np.zeros(4, np.uint8), np.zeros(1, np.uint8), np.zeros(1, np.uint8), 2)
+    assert e.value.code == h263mi.ERR_NO_DEVICE
+    with pytest.raises(h263mi.H263Error) as e:
+        h263mi.Batch(2, 64, 48)
+    assert e.value.code == h263mi.ERR_NO_DEVICE

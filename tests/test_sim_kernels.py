@@ -1,0 +1,166 @@
+"""Kernel phase logic (h263-rs_amd/csrc/*_kernel.inl) run on the CPU by tests/sim against the
+oracle: same tiling, LDS indexing, clamping and edge handling as the GPU build, without a
+GPU.  Bit-exact for every plane and RGBA byte.  (The GPU parity tests are in test_gpu_*.py.)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import recgen
+import simlib
+from oracle import oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SIZES = [(16, 16), (48, 32), (100, 60), (5, 4), (1, 1), (33, 17), (176, 144), (320, 240), (136, 40)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_recon_intra(w, h):
+    mbs, coeffs = recgen.intra_picture(w, h, seed=w * 31 + h)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, None)
+    st, got = simlib.recon(w, h, mbs, coeffs, None)
+    assert rc == 0 and st == 0
+    for g, e, name in zip(got, want, "Y Cb Cr".split()):
+        assert (g == e).all(), (name, np.flatnonzero(g != e)[:10])
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_recon_inter(w, h):
+    ref = recgen.random_planes(w, h, 77)
+    mbs, coeffs = recgen.inter_picture(w, h, seed=w * 13 + h, mv_range=70, p_4v=0.3, p_intra=0.15, quant=0)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+    st, got = simlib.recon(w, h, mbs, coeffs, ref)
+    assert rc == 0 and st == 0
+    for g, e, name in zip(got, want, "Y Cb Cr".split()):
+        assert (g == e).all(), (name, np.flatnonzero(g != e)[:10])
+
+
+def test_recon_short_picture_is_padded_and_errors_without_reference():
+    w, h = 64, 48
+    ref = recgen.random_planes(w, h, 3)
+    mbs, coeffs = recgen.inter_picture(w, h, seed=5, n_mbs=7)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+    st, got = simlib.recon(w, h, mbs, coeffs, ref)
+    assert rc == 0 and st == 0
+    for g, e in zip(got, want):
+        assert (g == e).all()
+    st, _ = simlib.recon(w, h, mbs, coeffs, None)
+    assert st & 1                                   # STATUS_INTER_WITHOUT_REFERENCE (gather.rs:149)
+
+
+def test_recon_kill_and_dc_special_cases():
+    w, h = 32, 16
+    mbs, coeffs = recgen.intra_picture(w, h, 9, classes=("full_sparse", "dc", "vert", "horiz"))
+    mbs[0]["kill"] = 0b100101
+    mbs[1]["intradc"][:] = 255                      # level 1024
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, None)
+    st, got = simlib.recon(w, h, mbs, coeffs, None)
+    assert rc == 0 and st == 0
+    for g, e in zip(got, want):
+        assert (g == e).all()
+
+
+def test_recon_all_dc_values_through_inter_dc_class():
+    # inter block whose only coefficient sits at zigzag 0 -> Dc(dequantised) (appendix B.6):
+    # sweep levels x quants over the whole dequantised range, prediction 0 and 255
+    w, h = 16 * 8, 16 * 8
+    for pred in (0, 255):
+        ref = tuple(np.full(n, pred, np.uint8) for n in (w * h, (w // 2) * (h // 2), (w // 2) * (h // 2)))
+        rng = np.random.default_rng(pred)
+        mbs = np.zeros(64, orc.MB_RECORD_DTYPE)
+        mbs["mb_type"] = 0
+        mbs["quant"] = rng.integers(1, 32, 64)
+        mbs["cbp"] = 0x3F
+        mbs["coeff_index"] = np.arange(64) * 6
+        coeffs = np.zeros((64 * 6, 64), np.int16)
+        coeffs[:, 0] = rng.integers(-127, 128, 64 * 6)
+        rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+        st, got = simlib.recon(w, h, mbs, coeffs, ref)
+        assert rc == 0 and st == 0
+        for g, e in zip(got, want):
+            assert (g == e).all()
+
+
+@pytest.mark.parametrize("w,h", [(11, 17), (16, 16), (100, 60), (9, 9), (10, 10), (8, 2), (1, 1), (200, 37),
+                                 (136, 40), (960, 20)])
+@pytest.mark.parametrize("strength", [1, 5, 12])
+def test_post_deblock_planes(w, h, strength):
+    planes = recgen.random_planes(w, h, w + h + strength)
+    _, got = simlib.post(w, h, planes, strength, want_rgba=False)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    for g, p, pw in zip(got, planes, (w, cw, cw)):
+        assert (g == orc.deblock(p, pw, strength)).all()
+
+
+def test_post_deblock_reference_image_luma_only():
+    img = json.load(open(os.path.join(GOLD, "deblock_reference_tests.json")))["image"]
+    data = np.array(img["data"], np.uint8)
+    for s in ("4", "8", "12"):
+        _, got = simlib.post(11, 17, (data, None, None), int(s), want_rgba=False, luma_only=True)
+        assert got[0].tolist() == img["expected"][s]
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 2), (3, 2), (3, 3), (4, 4), (5, 4), (100, 60), (133, 35), (176, 144)])
+@pytest.mark.parametrize("strength", [0, 7])
+def test_post_rgba(w, h, strength):
+    planes = recgen.random_planes(w, h, w * h)
+    rgba, _ = simlib.post(w, h, planes, strength, want_planes=False)
+    cw = (w + 1) // 2
+    if strength:
+        planes = tuple(orc.deblock(p, pw, strength) for p, pw in zip(planes, (w, cw, cw)))
+    assert (rgba == orc.yuv420_to_rgba(*planes, w)).all()
+
+
+def test_post_rgba_reference_pictures():
+    bt = json.load(open(os.path.join(GOLD, "bt601_reference_tests.json")))
+    for p in bt["pictures"]:
+        if not p["y"]:
+            continue
+        w = p["y_width"]
+        h = len(p["y"]) // w
+        rgba, _ = simlib.post(w, h, (np.array(p["y"], np.uint8), np.array(p["cb"], np.uint8),
+                                     np.array(p["cr"], np.uint8)), 0, want_planes=False)
+        assert rgba.tolist() == p["rgba"]
+
+
+def test_synth_records_decode_identically_in_sim_and_oracle():
+    w, h = 176, 144
+    ref = None
+    for frame, kind in enumerate((1, 2, 2)):                 # mixed I, then two P pictures
+        mbs, coeffs = simlib.synth_picture(kind, w, h, 3, frame)
+        rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+        st, got = simlib.recon(w, h, mbs, coeffs, ref)
+        assert rc == 0 and st == 0
+        for g, e in zip(got, want):
+            assert (g == e).all()
+        ref = want
+    mbs, coeffs = simlib.synth_picture(0, 48, 32, 0, 0)      # dense I
+    assert (mbs["cbp"] == 0x3F).all() and coeffs.shape[0] == 6 * 6
+    rc, want = orc.decode_picture(48, 32, mbs, coeffs, None)
+    st, got = simlib.recon(48, 32, mbs, coeffs, None)
+    assert all((g == e).all() for g, e in zip(got, want))
+
+
+def test_asan_build_runs_clean():
+    """The same phases under AddressSanitizer + UBSan (child process, libasan preloaded)."""
+    import subprocess
+    import sys
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    code = (
+        "import sys; sys.path[:0]=[%r,%r]\n"
+        "import numpy as np, recgen, simlib\n"
+        "for (w,h) in [(5,4),(33,17),(100,60),(136,40)]:\n"
+        "    ref=recgen.random_planes(w,h,1)\n"
+        "    mbs,co=recgen.inter_picture(w,h,seed=2,mv_range=90,p_4v=0.3,p_intra=0.2,quant=0)\n"
+        "    simlib.recon(w,h,mbs,co,ref,asan=True)\n"
+        "    mbs,co=recgen.intra_picture(w,h,seed=3)\n"
+        "    simlib.recon(w,h,mbs,co,None,asan=True)\n"
+        "    simlib.post(w,h,ref,6,asan=True)\n"
+        "    simlib.post(w,h,ref,0,asan=True)\n"
+        "print('asan-ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "asan-ok" in out.stdout, out.stderr[-3000:]

@@ -57,12 +57,18 @@ H263_HD void deblock_quartet(int &A, int &B, int &C, int &D, int strength, bool 
 // bt601.rs:12-59, one pixel -> packed R | G<<8 | B<<16 | 255<<24
 H263_HD uint32_t bt601_pixel(int y, int cb, int cr)
 {
-    const int gray = (y - 16) * 76309;
-    const int r = (gray + (cr - 128) * 104597 + 32768) >> 16;
-    const int g = (gray + (cr - 128) * -53279 + (cb - 128) * -25675 + 32768) >> 16;
-    const int b = (gray + (cb - 128) * 132201 + 32768) >> 16;
-    return (uint32_t)clampi(r, 0, 255) | ((uint32_t)clampi(g, 0, 255) << 8) |
-           ((uint32_t)clampi(b, 0, 255) << 16) | 0xff000000u;
+    const int gray = (y - 16) * 76309 + 32768;
+    const int r = gray + (cr - 128) * 104597;
+    const int g = gray + (cr - 128) * -53279 + (cb - 128) * -25675;
+    const int b = gray + (cb - 128) * 132201;
+    // clamp(v >> 16, 0, 255) == clamp(v, 0, 0xFFFFFF) >> 16 (the shift is monotone).  Written in
+    // this order on purpose: hipcc (ROCm 7.2) turns the shift-then-clamp form into the gfx950
+    // instruction v_ashr_pk_u8_i32, whose result for negative inputs did not match the 0 the
+    // reference expects (caught by the bt601.rs:206-207 golden on an MI355X).
+    const uint32_t R = (uint32_t)clampi(r, 0, 0xFFFFFF) >> 16;
+    const uint32_t G = (uint32_t)clampi(g, 0, 0xFFFFFF) >> 16;
+    const uint32_t B = (uint32_t)clampi(b, 0, 0xFFFFFF) >> 16;
+    return R | (G << 8) | (B << 16) | 0xff000000u;
 }
 
 // ---- phase 0: tile -> LDS ---------------------------------------------------------------

@@ -31,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "h263-rs_amd")):
 import numpy as np  # noqa: E402
 
 import h263mi  # noqa: E402
+import shard  # noqa: E402
 
 W, H = 1920, 1080
 MBS_PP = 120 * 68
@@ -154,33 +155,21 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     n = args.streams
-    wl = Workload(n, args.gop, rank * n, local_rank, stream)
+    my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU
+    wl = Workload(n, args.gop, my_streams[0], local_rank, stream)
     batch = h263mi.Batch(n, W, H, local_rank, stream)
     d_rgba = h263mi.DeviceBuffer(n * RGBA_BYTES, local_rank)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     run_steps(batch, wl, d_rgba, 0, args.warmup)
     batch.sync()
-    barrier()
     batch.timing_begin()
-    t0 = time.perf_counter()
-    run_steps(batch, wl, d_rgba, args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # barrier + synchronize | exactly K steps | synchronize + barrier; MAX over ranks
+    elapsed = shard.timed_region(dist, lambda: run_steps(batch, wl, d_rgba, args.warmup, args.steps),
+                                 torch.cuda.synchronize)
     kt = batch.timing_end()
     batch.sync()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    pictures = world * n * args.steps
+    pictures = shard.aggregate_pictures(dist, n * args.steps)
     value = pictures * MP_PER_PICTURE / elapsed
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region only)

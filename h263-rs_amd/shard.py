@@ -1,0 +1,55 @@
+"""Stream sharding and throughput aggregation for multi-GPU runs (one process per GPU).
+
+The path shards across independent streams only: stream `s` is pinned to one rank for
+its lifetime, its frame store never leaves that GPU's HBM, and the only collectives are the barrier
+around the timed region and the max-over-ranks reduction of the elapsed time.  Used by bench.py
+(backend "nccl" = RCCL) and covered by tests/test_multirank.py with two gloo ranks on CPU.
+"""
+import time
+
+
+def streams_of_rank(rank, world, streams_per_gpu, total_streams=None):
+    """Global stream ids decoded by `rank`.
+
+    Weak scaling (total_streams None): every rank owns `streams_per_gpu` streams, ids
+    rank*streams_per_gpu ... ; with a fixed total, stream s goes to rank s mod world."""
+    if total_streams is None:
+        return list(range(rank * streams_per_gpu, (rank + 1) * streams_per_gpu))
+    return [s for s in range(total_streams) if s % world == rank]
+
+
+def barrier(dist, sync_device=None):
+    if dist is not None and dist.is_initialized():
+        dist.barrier()
+    if sync_device is not None:
+        sync_device()
+
+
+def timed_region(dist, run, sync_device=None):
+    """barrier + device sync | run() | device sync + barrier; returns the MAX elapsed seconds over ranks."""
+    import torch
+    barrier(dist, sync_device)
+    t0 = time.perf_counter()
+    run()
+    if sync_device is not None:
+        sync_device()
+    if dist is not None and dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None and dist.is_initialized():
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def aggregate_pictures(dist, pictures_this_rank):
+    """Whole-job picture count (sum over ranks)."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return int(pictures_this_rank)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([pictures_this_rank], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

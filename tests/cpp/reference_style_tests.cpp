@@ -1,0 +1,157 @@
+// reference_style_tests.cpp -- the reference's own in-source tests for the hot path, re-run
+// against the GPU back-end through the C++ mirror of its API (h263-rs_amd/host/h263mi.hpp).
+// Test names and structure follow yuv/src/bt601.rs:198-483 and deblock/src/deblock.rs:320-558;
+// the expected DATA comes from tests/golden/*.json via a generated header (gen_golden_header.py),
+// nothing of the reference's source text is kept here.
+//
+// The reference tests call the per-quartet `process` and the 4-pixel `yuv_to_rgba_4x` directly;
+// those are private helpers there, so here each case is wrapped into the smallest picture that
+// routes it through the same arithmetic: a 1x16 image for `process` (scalar semantics apply to
+// rows >= 8*floor(h/8)), a 4x1 picture with one chroma pair for a single pixel.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../h263-rs_amd/host/h263mi.hpp"
+#include "golden_data.h"
+
+static int failures = 0;
+#define ASSERT_EQ(a, b, what)                                                     \
+    do {                                                                          \
+        if (!((a) == (b))) {                                                      \
+            std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, what);             \
+            failures++;                                                           \
+        }                                                                         \
+    } while (0)
+
+using Bytes = std::vector<uint8_t>;
+
+static std::tuple<uint8_t, uint8_t, uint8_t> yuv_to_rgb(uint8_t y, uint8_t cb, uint8_t cr)
+{
+    Bytes rgba = yuv::bt601::yuv420_to_rgba({y, y, y, y}, {cb, cb}, {cr, cr}, 4);
+    for (int p = 1; p < 4; p++)
+        for (int c = 0; c < 4; c++) ASSERT_EQ(rgba[4 * p + c], rgba[c], "all four pixels equal");
+    ASSERT_EQ(rgba[3], 255, "alpha");
+    return {rgba[0], rgba[1], rgba[2]};
+}
+
+static void process(uint8_t &a, uint8_t &b, uint8_t &c, uint8_t &d, uint8_t strength)
+{
+    Bytes img(16);
+    for (int i = 0; i < 6; i++) img[i] = a;
+    img[6] = a; img[7] = b; img[8] = c; img[9] = d;
+    for (int i = 10; i < 16; i++) img[i] = d;
+    Bytes out = deblock::deblock(img, 16, strength);
+    a = out[6]; b = out[7]; c = out[8]; d = out[9];
+}
+
+static void test_yuv_to_rgb()                      // bt601.rs:199-225
+{
+    for (const auto &c : GOLD_SINGLE_PIXEL) {
+        auto [r, g, b] = yuv_to_rgb(c[0], c[1], c[2]);
+        ASSERT_EQ(r, c[3], "r"); ASSERT_EQ(g, c[4], "g"); ASSERT_EQ(b, c[5], "b");
+    }
+}
+
+static void test_yuv420_to_rgba_tiny_and_medium()  // bt601.rs:329-483
+{
+    ASSERT_EQ(yuv::bt601::yuv420_to_rgba({}, {}, {}, 0).size(), (size_t)0, "empty picture");
+    for (const auto &p : GOLD_PICTURES) {
+        Bytes out = yuv::bt601::yuv420_to_rgba(p.y, p.cb, p.cr, p.y_width);
+        ASSERT_EQ(out, p.rgba, "picture");
+    }
+}
+
+static void test_process_const()                   // deblock.rs:323-334
+{
+    for (int val = 0; val <= 255; val += 3)
+        for (int s = 1; s <= 12; s += 11) {
+            uint8_t a = val, b = val, c = val, d = val;
+            process(a, b, c, d, s);
+            ASSERT_EQ(a, val, "const a"); ASSERT_EQ(b, val, "const b"); ASSERT_EQ(c, val, "const c"); ASSERT_EQ(d, val, "const d");
+        }
+}
+
+static void test_process()                         // deblock.rs:352-439
+{
+    for (const auto &r : GOLD_PROCESS_ROWS) {
+        uint8_t a = r[0], b = r[1], c = r[2], d = r[3];
+        process(a, b, c, d, r[4]);
+        ASSERT_EQ(a, r[5], "a"); ASSERT_EQ(b, r[6], "b"); ASSERT_EQ(c, r[7], "c"); ASSERT_EQ(d, r[8], "d");
+        a = r[0]; b = r[1]; c = r[2]; d = r[3];
+        process(d, c, b, a, r[4]);                   // direction symmetry
+        ASSERT_EQ(a, r[5], "rev a"); ASSERT_EQ(b, r[6], "rev b"); ASSERT_EQ(c, r[7], "rev c"); ASSERT_EQ(d, r[8], "rev d");
+        a = 255 - r[0]; b = 255 - r[1]; c = 255 - r[2]; d = 255 - r[3];
+        process(a, b, c, d, r[4]);                   // value symmetry
+        ASSERT_EQ(255 - a, r[5], "inv a"); ASSERT_EQ(255 - b, r[6], "inv b"); ASSERT_EQ(255 - c, r[7], "inv c"); ASSERT_EQ(255 - d, r[8], "inv d");
+    }
+}
+
+static void test_deblock()                         // deblock.rs:442-558
+{
+    ASSERT_EQ(deblock::deblock(GOLD_IMAGE, 11, 4), GOLD_EXPECTED_4, "strength 4");
+    ASSERT_EQ(deblock::deblock(GOLD_IMAGE, 11, 8), GOLD_EXPECTED_8, "strength 8");
+    ASSERT_EQ(deblock::deblock(GOLD_IMAGE, 11, 12), GOLD_EXPECTED_12, "strength 12");
+    for (int q = 0; q < 32; q++) ASSERT_EQ(deblock::QUANT_TO_STRENGTH[q], GOLD_QUANT_TO_STRENGTH[q], "Table J.2");
+}
+
+static void test_state_api()                       // state.rs:42-78, gather.rs:149
+{
+    h263::H263State st(h263::DecoderOption::SORENSON_SPARK_BITSTREAM);
+    ASSERT_EQ(st.is_sorenson(), true, "is_sorenson");
+    ASSERT_EQ(st.get_last_picture().has_value(), false, "no picture yet");
+    ASSERT_EQ(st.get_reference_picture().has_value(), false, "no reference yet");
+    // QCIF I picture of DC-only intra blocks: every block is flat at its INTRADC code (255 -> 128)
+    std::vector<h263mi_mb_record> mbs(99);
+    for (size_t i = 0; i < mbs.size(); i++) {
+        mbs[i] = h263mi_mb_record{};
+        mbs[i].mb_type = H263MI_MB_INTRA;
+        mbs[i].quant = 8;
+        for (int b = 0; b < 6; b++) mbs[i].intradc[b] = (uint8_t)(1 + (i * 6 + b) % 127);
+    }
+    mbs[0].intradc[0] = 255;
+    h263mi_picture_desc d{176, 144, H263MI_PICTURE_I, 8, 0, 0, 7, 0};
+    st.submit_picture(d, mbs, {});
+    auto pic = st.get_last_picture();
+    ASSERT_EQ(pic.has_value(), true, "picture");
+    ASSERT_EQ(pic->luma_samples_per_row(), (size_t)176, "luma_samples_per_row");
+    ASSERT_EQ(pic->chroma_samples_per_row(), (size_t)88, "chroma_samples_per_row");
+    ASSERT_EQ(pic->as_luma().size(), (size_t)176 * 144, "luma size");
+    ASSERT_EQ(pic->as_luma()[0], 128, "code 255 -> 1024 -> 128");
+    ASSERT_EQ(pic->as_luma()[8], mbs[0].intradc[1], "block 1 flat at its code");
+    ASSERT_EQ(pic->as_chroma_b()[0], mbs[0].intradc[4], "Cb flat at its code");
+    // an inter picture on a fresh state has no reference: Error::UncodedIFrameBlocks, state unchanged
+    h263::H263State fresh(h263::DecoderOption::SORENSON_SPARK_BITSTREAM);
+    std::vector<h263mi_mb_record> inter(99, h263mi_mb_record{});
+    for (auto &m : inter) m.quant = 1;
+    bool threw = false;
+    try {
+        fresh.submit_picture(h263mi_picture_desc{176, 144, H263MI_PICTURE_P, 8, 0, 0, 1, 0}, inter, {});
+    } catch (const h263::Error &e) {
+        threw = e.code == H263MI_ERR_UNCODED_IFRAME_BLOCKS;
+    }
+    ASSERT_EQ(threw, true, "UncodedIFrameBlocks");
+    ASSERT_EQ(fresh.get_last_picture().has_value(), false, "state unchanged after error");
+    // zero-motion uncoded P picture on the first state is an exact copy
+    st.submit_picture(h263mi_picture_desc{176, 144, H263MI_PICTURE_P, 8, 0, 0, 8, 0}, inter, {});
+    auto p2 = st.get_last_picture();
+    ASSERT_EQ(p2->as_luma(), pic->as_luma(), "copy Y");
+    ASSERT_EQ(p2->as_chroma_r(), pic->as_chroma_r(), "copy Cr");
+    ASSERT_EQ(st.render_rgba(0), yuv::bt601::yuv420_to_rgba(p2->as_luma(), p2->as_chroma_b(), p2->as_chroma_r(), 176), "render == convert");
+}
+
+int main()
+{
+    int n = 0;
+    if (h263mi_device_count(&n) != H263MI_OK || n < 1) {
+        std::printf("no HIP device: the back-end has no CPU fallback\n");
+        return 2;
+    }
+    test_yuv_to_rgb();
+    test_yuv420_to_rgba_tiny_and_medium();
+    test_process_const();
+    test_process();
+    test_deblock();
+    test_state_api();
+    std::printf(failures ? "FAILED (%d)\n" : "all reference-style tests passed\n", failures);
+    return failures ? 1 : 0;
+}

@@ -85,3 +85,26 @@ def test_no_gpu_fails_loudly_and_never_falls_back():
     with pytest.raises(h263mi.H263Error) as e:
         h263mi.Batch(2, 64, 48)
     assert e.value.code == h263mi.ERR_NO_DEVICE
+
+
+def test_kernel_isa_has_no_fused_multiply_add_and_no_ashr_pk():
+    """Bit-exactness guard on the generated gfx950 code: the reference IDCT rounds every product and
+    every sum separately (idct.rs:52-65), so no v_fma/v_mac/v_mad_f32 may appear; and hipcc's
+    v_ashr_pk_u8_i32 lowering is known to be wrong on gfx950 (tools/probes/probe_ashr_pk.hip)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "h263-rs_amd", "csrc", "kernels.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                               "-fno-fast-math", "-S", "--cuda-device-only", "-x", "hip", src, "-o", out],
+                              stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    body = asm[asm.index("k_recon"):]
+    for bad in ("v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_mad_f32", "v_pk_fma_f32", "v_fma_mix", "v_ashr_pk_"):
+        assert bad not in asm, bad
+    assert "v_pk_mul_f32" in body or "v_mul_f32" in body

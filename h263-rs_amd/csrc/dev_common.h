@@ -91,7 +91,7 @@ struct ReconArgs {
     uint32_t mbs_per_picture;
     uint32_t has_ref;            // 0: inter macroblocks are an error
     uint32_t tiles_x, tiles_y;
-    uint32_t pad;
+    uint32_t debug_flags;        // diagnosis only (env H263MI_DEBUG_RECON): 1 = no reference loads, 2 = no stores, 4 = no coefficient loads
 };
 
 // ---------------------------------------------------------------------------
@@ -106,7 +106,7 @@ struct PostArgs {
     uint32_t strength;           // 0 = no deblocking
     uint32_t tiles_x, tiles_y;
     uint32_t luma_only;          // standalone deblock() of a single plane
-    uint32_t pad;
+    uint32_t debug_flags;        // diagnosis only (env H263MI_DEBUG_POST): 1 = no global loads, 2 = no stores
 };
 
 // ---------------------------------------------------------------------------

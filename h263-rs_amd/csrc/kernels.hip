@@ -2,64 +2,115 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
 #include "kernels.h"
 
+#include <stdlib.h>
+
 #include "post_kernel.inl"
 #include "recon_kernel.inl"
 #include "synth.inl"
 
 namespace h263mi {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
+// for every outstanding global load and store of the wave -- which would serialise the prefetch of
+// the next tile (and the write latency of the previous one) behind each barrier.  Global loads are
+// still waited for where their registers are first used (the compiler tracks vmcnt itself).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------
-// k_recon: grid = (tiles per picture, pictures), 256 threads
+// k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
+// workgroup, tiles taken in XCD-aware order (see k_post below).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 {
-    __shared__ __attribute__((aligned(16))) ReconSmem s;
-    const int tid = threadIdx.x, tile = blockIdx.x, pic = blockIdx.y;
-    recon_phase_load(a, s, tid, tile, pic);
-    __syncthreads();
-    recon_phase_mark(a, s, tid);
-    __syncthreads();
-    recon_phase_compact(a, s, tid);
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ReconWave &s = waves[wave];
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures;
+    const uint32_t chunk = (total + 7) / 8, xcd = blockIdx.x & 7;
+    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
+    if (t >= chunk || g >= total) return;
+    const int tile = (int)(g % tpp);
+    WavePos p;
+    p.pic = (int)(g / tpp);
+    p.mbx0 = (tile % (int)a.tiles_x) * TILE_MBX;
+    p.mby = (tile / (int)a.tiles_x) * TILE_MBY + (wave >> 1);
+    p.half = wave & 1;
+    if (p.mby >= (int)a.L.mbh) return;
+    p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
+
+    recon_phase_load(a, s, lane, p);
+    recon_phase_mark(a, s, lane, p);
+    recon_phase_compact(a, s, lane);
+    WaveFetch f;
+    recon_phase_fetch(a, s, f, lane, p);          // every global load of the wave is in flight from here
     const int n_active = recon_n_active(s);
     for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
-        recon_phase_idct_rows(a, s, tid, pic, round);
-        __syncthreads();
-        recon_phase_idct_cols(a, s, tid, round);
-        __syncthreads();
+        recon_phase_idct_rows(a, s, f, lane, p, round);
+        recon_phase_idct_cols(a, s, lane, round);
     }
-    recon_phase_output(a, s, tid, tile, pic);
+    recon_phase_output(a, s, f, lane, p);
 }
 
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
 {
-    dim3 grid(args.tiles_x * args.tiles_y, args.n_pictures, 1);
-    hipLaunchKernelGGL(k_recon, grid, dim3(RECON_THREADS), 0, stream, args);
+    static const uint32_t env_debug = [] {
+        const char *e = getenv("H263MI_DEBUG_RECON");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    ReconArgs a = args;
+    a.debug_flags |= env_debug;
+    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures;
+    const uint32_t chunk = (total + 7) / 8;
+    hipLaunchKernelGGL(k_recon, dim3(chunk * 8), dim3(RECON_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
-// k_post: grid = (tiles per picture, pictures), 256 threads
+// k_post: persistent, 256 threads, grid = 8 x (workgroups per XCD).
+//
+// Work order is XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names
+// the group that shares an L2 -- a speed assumption only, never correctness), so XCD k walks the
+// contiguous range [k*chunk, (k+1)*chunk) of the (picture, tile) list and its workgroups sit on
+// neighbouring tiles at any moment: the cache lines that the 4-pixel tile offset makes two tiles
+// share are then fetched once per L2 instead of once per XCD.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 {
-    __shared__ __attribute__((aligned(16))) PostSmem s;
-    const int tid = threadIdx.x, tile = blockIdx.x, pic = blockIdx.y;
-    post_phase_load(a, s, tid, tile, pic);
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    PostStrip &s = strips[wave];
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures;
+    const uint32_t chunk = (total + 7) / 8, xcd = blockIdx.x & 7;
+    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
+    if (t >= chunk || g >= total) return;
+    const int pic = (int)(g / tpp), tile = (int)(g % tpp);
+    const int sx = tile % (int)a.tiles_x, sy = (tile / (int)a.tiles_x) * POST_WAVES + wave;
+    if (sy >= (int)post_strips_y(a.L.height)) return;
+    // no workgroup barrier anywhere: the wave owns its strip from load to store
+    PostFetch pf;
+    post_phase_fetch(a, pf, lane, sx, sy, pic);
+    post_phase_commit(a, s, pf, lane);
     if (a.strength) {
-        post_phase_hedges(a, s, tid, tile);
-        __syncthreads();
-        post_phase_vedges(a, s, tid, tile);
-        __syncthreads();
+        post_phase_hedges(a, s, lane, sx, sy);
+        post_phase_vedges(a, s, lane, sx, sy);
     }
-    post_phase_store(a, s, tid, tile, pic);
+    post_phase_store(a, s, lane, sx, sy, pic);
 }
 
 hipError_t launch_post(const PostArgs &args, hipStream_t stream)
 {
-    dim3 grid(args.tiles_x * args.tiles_y, args.n_pictures, 1);
-    hipLaunchKernelGGL(k_post, grid, dim3(POST_THREADS), 0, stream, args);
+    static const uint32_t env_debug = [] {
+        const char *e = getenv("H263MI_DEBUG_POST");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    PostArgs a = args;
+    a.debug_flags |= env_debug;
+    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures;
+    const uint32_t chunk = (total + 7) / 8;
+    hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -4,12 +4,15 @@
 // deblock_vert 185-299, kernel process/process_simd 29-42 / 99-127) applied to each plane
 // and yuv::bt601::yuv420_to_rgba (yuv/src/bt601.rs:105-196, yuv_to_rgba_4x 12-59).
 //
-// One workgroup owns a 128x32 luma tile (+ the matching 64x16 chroma tiles) whose origin
-// is shifted to (4,4) mod 16.  Every filtered pixel group -- rows edge-2..edge+1 of a
-// horizontal block edge, columns edge-2..edge+1 of a vertical one -- then lies entirely
-// inside one tile for luma (edges at multiples of 8) AND for chroma (tile origin (2,2)
-// mod 8), so the two filter passes run in LDS with no halo and no second pass over HBM:
-// load tile -> H-edges -> V-edges -> convert -> 16-byte RGBA stores.
+// Work unit = one WAVE = one strip: 128 luma columns x 8 luma rows plus the matching 64x4
+// strips of Cb and Cr, with the strip origin at x = 4 (mod 128), y = 4 (mod 8).  Every
+// filtered pixel group -- rows edge-2..edge+1 of a horizontal block edge, columns
+// edge-2..edge+1 of a vertical one -- then lies wholly inside one strip, for luma (edges at
+// multiples of 8) AND for chroma (strip origin (2,2) mod (8,4)).  So a wave needs nothing from
+// any other wave: load strip -> H-edge -> V-edges -> convert -> 16-byte RGBA stores, through
+// 1.5 KB of wave-private LDS, with NO workgroup barrier (DS operations of one wave execute in
+// order, which is all the cross-lane hand-offs need).  A workgroup is four such waves (a
+// 128x32 tile) only so that the XCD-aware work order of kernels.hip keeps neighbours together.
 //
 // The reference mixes two integer semantics by position: its
 // SIMD lanes use arithmetic shifts (floor), its scalar tails use `/` (truncation).
@@ -22,14 +25,18 @@
 namespace h263mi {
 
 constexpr int POST_THREADS = 256;
-constexpr int POST_TW = 128, POST_TH = 32;          // luma tile
-constexpr int POST_CW = 64, POST_CH = 16;           // chroma tile
-constexpr int POST_OX = POST_TW - 4, POST_OY = POST_TH - 4;   // tile (tx,ty) starts at tx*TW - OX, ty*TH - OY
+constexpr int POST_TW = 128, POST_TH = 32;          // luma tile of a workgroup = 4 strips of 8 rows
+constexpr int POST_SH = 8;                          // luma rows per strip (one wave)
+constexpr int POST_CW = 64, POST_CSH = 4;           // chroma strip
+constexpr int POST_OX = POST_TW - 4;                // strip column sx starts at sx*128 - 124
+constexpr int POST_WAVES = POST_THREADS / 64;
 
-struct PostSmem {
-    uint8_t y[POST_TH * POST_TW];
-    uint8_t c[2][POST_CH * POST_CW];
+struct PostStrip {
+    uint8_t y[POST_SH * POST_TW];
+    uint8_t c[2][POST_CSH * POST_CW];
 };
+
+H263_HD uint32_t post_strips_y(uint32_t h) { return (h + 4 + POST_SH - 1) / POST_SH; }
 
 // One A,B,C,D quartet (deblock.rs:29-42 / 99-127).  floor_sem selects the SIMD-lane
 // semantics (>>) over the scalar ones (/).
@@ -71,103 +78,117 @@ H263_HD uint32_t bt601_pixel(int y, int cb, int cr)
     return R | (G << 8) | (B << 16) | 0xff000000u;
 }
 
-// ---- phase 0: tile -> LDS ---------------------------------------------------------------
-H263_DEV void post_phase_load(const PostArgs &a, PostSmem &s, int tid, int tile, int pic)
+// ---- phase 0: strip -> registers -> LDS -----------------------------------------------------
+struct PostFetch {
+    uint32_t y[4];
+    uint16_t c[4];
+};
+
+// lane = 16 luma bytes (row = lane/8) and 8 chroma bytes (plane = lane/32, row = (lane/8)%4)
+H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx, int sy, int pic)
 {
-    const int tx = tile % (int)a.tiles_x, ty = tile / (int)a.tiles_x;
     const uint8_t *frame = a.frames + (size_t)pic * a.L.frame_bytes;
-    const int xl = tx * POST_TW - POST_OX, yl = ty * POST_TH - POST_OY;
-    // luma: 32 rows x 128 B = 256 lanes x 16 B (4 dwords; the origin is only 4-byte aligned)
+    const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
+    if (a.debug_flags & 1) {                                  // diagnosis: compute and stores without the loads
+#pragma unroll
+        for (int q = 0; q < 4; q++) { r.y[q] = 0x40506070u + lane + sy; r.c[q] = (uint16_t)(0x8070 + lane); }
+        return;
+    }
     {
-        const int row = tid >> 3, col = (tid & 7) * 16;
+        const int row = lane >> 3, col = (lane & 7) * 16;
         const int gy = yl + row;
-        uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) r.y[q] = 0;
         if (gy >= 0 && gy < (int)a.L.rows_y) {
             const uint8_t *src = frame + (size_t)gy * a.L.pitch_y;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int gx = xl + col + 4 * q;
-                if (gx >= 0 && gx + 4 <= (int)a.L.pitch_y) v[q] = *reinterpret_cast<const uint32_t *>(src + gx);
+                if (gx >= 0 && gx + 4 <= (int)a.L.pitch_y) r.y[q] = *reinterpret_cast<const uint32_t *>(src + gx);
             }
         }
-        *reinterpret_cast<uint4 *>(&s.y[row * POST_TW + col]) = make_uint4(v[0], v[1], v[2], v[3]);
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) r.c[q] = 0;
     if (a.luma_only) return;
-    // chroma: 2 planes x 16 rows x 64 B = 256 lanes x 8 B (origin 2-byte aligned: byte-pair loads)
     {
-        const int plane = tid >> 7, row = (tid >> 3) & 15, col = (tid & 7) * 8;
+        const int plane = lane >> 5, row = (lane >> 3) & 3, col = (lane & 7) * 8;
         const int cxl = xl / 2, cyl = yl / 2;                 // xl, yl are even (and may be negative)
         const int gy = cyl + row;
         const uint8_t *src = frame + (plane ? a.L.off_cr : a.L.off_cb) + (size_t)(gy < 0 ? 0 : gy) * a.L.pitch_c;
-        uint16_t v[4] = {0, 0, 0, 0};
         if (gy >= 0 && gy < (int)a.L.rows_c) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int gx = cxl + col + 2 * q;
-                if (gx >= 0 && gx + 2 <= (int)a.L.pitch_c) v[q] = *reinterpret_cast<const uint16_t *>(src + gx);
+                if (gx >= 0 && gx + 2 <= (int)a.L.pitch_c) r.c[q] = *reinterpret_cast<const uint16_t *>(src + gx);
             }
         }
-        uint64_t packed = (uint64_t)v[0] | ((uint64_t)v[1] << 16) | ((uint64_t)v[2] << 32) | ((uint64_t)v[3] << 48);
+    }
+}
+
+H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch &r, int lane)
+{
+    {
+        const int row = lane >> 3, col = (lane & 7) * 16;
+        *reinterpret_cast<uint4 *>(&s.y[row * POST_TW + col]) = make_uint4(r.y[0], r.y[1], r.y[2], r.y[3]);
+    }
+    if (a.luma_only) return;
+    {
+        const int plane = lane >> 5, row = (lane >> 3) & 3, col = (lane & 7) * 8;
+        uint64_t packed = (uint64_t)r.c[0] | ((uint64_t)r.c[1] << 16) | ((uint64_t)r.c[2] << 32) | ((uint64_t)r.c[3] << 48);
         *reinterpret_cast<uint64_t *>(&s.c[plane][row * POST_CW + col]) = packed;
     }
 }
 
-// filter 4 neighbouring columns of one horizontal edge held in LDS
-H263_DEV void hfilter4(uint8_t *t, int pitch, int row_c, int col, int strength, int gx0, int floor_cols, int w)
+// filter 2 neighbouring columns of the horizontal edge whose A row is `row_a`
+H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, int gx0, int floor_cols, int w)
 {
-    uint32_t ra = *reinterpret_cast<uint32_t *>(t + (row_c - 2) * pitch + col);
-    uint32_t rb = *reinterpret_cast<uint32_t *>(t + (row_c - 1) * pitch + col);
-    uint32_t rc = *reinterpret_cast<uint32_t *>(t + (row_c)*pitch + col);
-    uint32_t rd = *reinterpret_cast<uint32_t *>(t + (row_c + 1) * pitch + col);
-    uint32_t oa = 0, ob = 0, oc = 0, od = 0;
+    uint32_t r[4], o[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int A = (ra >> (8 * k)) & 0xff, B = (rb >> (8 * k)) & 0xff, C = (rc >> (8 * k)) & 0xff, D = (rd >> (8 * k)) & 0xff;
-        int gx = gx0 + k;
+    for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        int A = (r[0] >> (8 * k)) & 0xff, B = (r[1] >> (8 * k)) & 0xff, C = (r[2] >> (8 * k)) & 0xff, D = (r[3] >> (8 * k)) & 0xff;
+        const int gx = gx0 + k;
         if (gx >= 0 && gx < w) deblock_quartet(A, B, C, D, strength, gx < floor_cols);
-        oa |= (uint32_t)A << (8 * k);
-        ob |= (uint32_t)B << (8 * k);
-        oc |= (uint32_t)C << (8 * k);
-        od |= (uint32_t)D << (8 * k);
+        o[0] |= (uint32_t)A << (8 * k);
+        o[1] |= (uint32_t)B << (8 * k);
+        o[2] |= (uint32_t)C << (8 * k);
+        o[3] |= (uint32_t)D << (8 * k);
     }
-    *reinterpret_cast<uint32_t *>(t + (row_c - 2) * pitch + col) = oa;
-    *reinterpret_cast<uint32_t *>(t + (row_c - 1) * pitch + col) = ob;
-    *reinterpret_cast<uint32_t *>(t + (row_c)*pitch + col) = oc;
-    *reinterpret_cast<uint32_t *>(t + (row_c + 1) * pitch + col) = od;
+#pragma unroll
+    for (int q = 0; q < 4; q++) *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col) = (uint16_t)o[q];
 }
 
-// ---- phase 1: horizontal block edges (deblock_horiz, deblock.rs:136-181) ------------------
-H263_DEV void post_phase_hedges(const PostArgs &a, PostSmem &s, int tid, int tile)
+// ---- phase 1: the horizontal block edge of the strip (deblock_horiz, deblock.rs:136-181) ------
+H263_DEV void post_phase_hedges(const PostArgs &a, PostStrip &s, int lane, int sx, int sy)
 {
-    const int tx = tile % (int)a.tiles_x, ty = tile / (int)a.tiles_x;
-    const int xl = tx * POST_TW - POST_OX, yl = ty * POST_TH - POST_OY;
+    const int xl = sx * POST_TW - POST_OX;
     const int strength = (int)a.strength;
-    if (tid < 128) {
-        // luma: 4 edges (tile rows 4, 12, 20, 28) x 32 column groups of 4
-        const int e = tid >> 5, cg = tid & 31;
-        const int row_c = 4 + 8 * e, gy = yl + row_c;          // picture row of the "C" samples
-        const int w = (int)a.L.width, h = (int)a.L.height;
-        if (gy >= 8 && gy + 1 <= h - 1)                        // edge_y <= height - 2 (deblock.rs:140)
-            hfilter4(s.y, POST_TW, row_c, cg * 4, strength, xl + cg * 4, (w / 8) * 8, w);
-    } else if (tid < 192 && !a.luma_only) {
-        // chroma: 2 planes x 2 edges (tile rows 6, 14) x 16 column groups
-        const int q = tid - 128, plane = q >> 5, e = (q >> 4) & 1, cg = q & 15;
-        const int row_c = 6 + 8 * e, gy = yl / 2 + row_c;
-        const int w = (int)a.L.cwidth, h = (int)a.L.cheight;
-        if (gy >= 8 && gy + 1 <= h - 1)
-            hfilter4(s.c[plane], POST_CW, row_c, cg * 4, strength, xl / 2 + cg * 4, (w / 8) * 8, w);
+    {
+        // luma: the edge's C row is picture row 8*sy = strip row 4; every lane takes 2 columns
+        const int gy = sy * POST_SH, w = (int)a.L.width, h = (int)a.L.height;
+        if (gy >= 8 && gy <= h - 2)                                      // edge_y <= height - 2 (deblock.rs:140)
+            hfilter2(s.y, POST_TW, 2, lane * 2, strength, xl + lane * 2, (w / 8) * 8, w);
+    }
+    if (!a.luma_only && (sy & 1) == 0) {
+        // chroma strip rows [4*sy-2, 4*sy+2) hold an edge only when 4*sy is a multiple of 8
+        const int gy = sy * POST_CSH, w = (int)a.L.cwidth, h = (int)a.L.cheight;
+        const int plane = lane >> 5, col = (lane & 31) * 2;
+        if (gy >= 8 && gy <= h - 2)
+            hfilter2(s.c[plane], POST_CW, 0, col, strength, xl / 2 + col, (w / 8) * 8, w);
     }
 }
 
 // ---- phase 2: vertical block edges (deblock_vert, deblock.rs:185-299) ----------------------
-H263_DEV void post_phase_vedges(const PostArgs &a, PostSmem &s, int tid, int tile)
+H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int sx, int sy)
 {
-    const int tx = tile % (int)a.tiles_x, ty = tile / (int)a.tiles_x;
-    const int xl = tx * POST_TW - POST_OX, yl = ty * POST_TH - POST_OY;
+    const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
     const int strength = (int)a.strength;
-    // luma: 32 rows x 16 edges; the quartet sits in bytes 2..5 of an aligned 8-byte window
+    // luma: 8 rows x 16 edges; the quartet sits in bytes 2..5 of an aligned 8-byte window
+#pragma unroll
     for (int it = 0; it < 2; it++) {
-        const int item = it * POST_THREADS + tid, row = item >> 4, j = item & 15;
+        const int row = (lane >> 4) + 4 * it, j = lane & 15;
         const int gy = yl + row, gxa = xl + 8 * j + 2;         // picture column of the "A" sample
         const int w = (int)a.L.width, h = (int)a.L.height;
         // A..D = columns 8k-2 .. 8k+1 with k >= 1 and 8k+1 <= w-1 (chunks of row[2..], deblock.rs:281)
@@ -181,9 +202,9 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostSmem &s, int tid, int til
         }
     }
     if (a.luma_only) return;
-    // chroma: 2 planes x 16 rows x 8 edges; the quartet is bytes 4..7 of an aligned 8-byte window
+    // chroma: 2 planes x 4 rows x 8 edges; the quartet is bytes 4..7 of an aligned 8-byte window
     {
-        const int plane = tid >> 7, row = (tid >> 3) & 15, j = tid & 7;
+        const int plane = lane >> 5, row = (lane >> 3) & 3, j = lane & 7;
         const int gy = yl / 2 + row, gxa = xl / 2 + 8 * j + 4;
         const int w = (int)a.L.cwidth, h = (int)a.L.cheight;
         if (gy >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
@@ -197,16 +218,17 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostSmem &s, int tid, int til
 }
 
 // ---- phase 3: BT.601 -> RGBA, optional filtered planes -------------------------------------
-H263_DEV void post_phase_store(const PostArgs &a, PostSmem &s, int tid, int tile, int pic)
+H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx, int sy, int pic)
 {
-    const int tx = tile % (int)a.tiles_x, ty = tile / (int)a.tiles_x;
-    const int xl = tx * POST_TW - POST_OX, yl = ty * POST_TH - POST_OY;
+    const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
     const int w = (int)a.L.width, h = (int)a.L.height, cw = (int)a.L.cwidth, ch = (int)a.L.cheight;
 
     if (a.rgba) {
         uint8_t *rgba = a.rgba + (size_t)pic * w * h * 4;
+#pragma unroll
         for (int it = 0; it < 4; it++) {
-            const int item = it * POST_THREADS + tid, row = item >> 5, g = item & 31;
+            // 32 consecutive lanes write 512 contiguous bytes of one RGBA row
+            const int item = it * 64 + lane, row = item >> 5, g = item & 31;
             const int gy = yl + row, gx = xl + 4 * g;
             if (gy < 0 || gy >= h || gx < 0 || gx >= w) continue;
             const uint32_t yv = *reinterpret_cast<const uint32_t *>(&s.y[row * POST_TW + 4 * g]);
@@ -218,6 +240,7 @@ H263_DEV void post_phase_store(const PostArgs &a, PostSmem &s, int tid, int tile
             for (int k = 0; k < 4; k++)
                 px[k] = bt601_pixel((yv >> (8 * k)) & 0xff, (cbv >> (8 * (k >> 1))) & 0xff, (crv >> (8 * (k >> 1))) & 0xff);
             uint8_t *dst = rgba + ((size_t)gy * w + gx) * 4;
+            if ((a.debug_flags & 2) && px[0] != 0x12345678u) continue;   // diagnosis: loads and compute without the stores
             if (gx + 4 <= w && (w & 3) == 0) {
                 *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
             } else {
@@ -229,18 +252,18 @@ H263_DEV void post_phase_store(const PostArgs &a, PostSmem &s, int tid, int tile
         // tightly packed Y | Cb | Cr, as deblock() returns them (deblock.rs:305-315)
         uint8_t *out = a.planes_out + (size_t)pic * ((size_t)w * h + 2 * (size_t)cw * ch);
         for (int it = 0; it < 4; it++) {
-            const int item = it * POST_THREADS + tid, row = item >> 5, g = item & 31;
+            const int item = it * 64 + lane, row = item >> 5, g = item & 31;
             const int gy = yl + row, gx = xl + 4 * g;
             if (gy < 0 || gy >= h || gx < 0) continue;
             for (int k = 0; k < 4 && gx + k < w; k++) out[(size_t)gy * w + gx + k] = s.y[row * POST_TW + 4 * g + k];
         }
         if (!a.luma_only) {
             for (int it = 0; it < 2; it++) {
-                const int item = it * POST_THREADS + tid, plane = item >> 8, row = (item >> 4) & 15, g = item & 15;
+                const int item = it * 64 + lane, plane = item >> 6, row = (item >> 4) & 3, g = item & 15;
                 const int gy = yl / 2 + row, gx = xl / 2 + 4 * g;
                 if (gy < 0 || gy >= ch) continue;
                 uint8_t *o = out + (size_t)w * h + (size_t)plane * cw * ch;
-                // the chroma tile origin is 2 mod 4: a group of 4 may straddle column 0
+                // the chroma strip origin is 2 mod 4: a group of 4 may straddle column 0
                 for (int k = 0; k < 4; k++)
                     if (gx + k >= 0 && gx + k < cw) o[(size_t)gy * cw + gx + k] = s.c[plane][row * POST_CW + 4 * g + k];
             }

@@ -35,20 +35,35 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
     a.has_ref = has_ref;
     a.tiles_x = (a.L.mbw + TILE_MBX - 1) / TILE_MBX;
     a.tiles_y = (a.L.mbh + TILE_MBY - 1) / TILE_MBY;
-    ReconSmem *s = (ReconSmem *)aligned_alloc(16, (sizeof(ReconSmem) + 15) / 16 * 16);
-    for (uint32_t pic = 0; pic < n_pictures; pic++)
-        for (uint32_t tile = 0; tile < a.tiles_x * a.tiles_y; tile++) {
+    ReconWave *s = (ReconWave *)aligned_alloc(16, (sizeof(ReconWave) + 15) / 16 * 16);
+    // same work decomposition as kernels.hip::k_recon: XCD-ordered tiles, 4 independent waves per tile
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * n_pictures, chunk = (total + 7) / 8;
+    static WaveFetch f[64];
+    for (uint32_t wg = 0; wg < chunk * 8; wg++) {
+        const uint32_t xcd = wg & 7, t = wg >> 3, g = xcd * chunk + t;
+        if (t >= chunk || g >= total) continue;
+        const int tile = g % tpp;
+        for (int wave = 0; wave < RECON_WAVES; wave++) {
+            WavePos p;
+            p.pic = g / tpp;
+            p.mbx0 = (tile % (int)a.tiles_x) * TILE_MBX;
+            p.mby = (tile / (int)a.tiles_x) * TILE_MBY + (wave >> 1);
+            p.half = wave & 1;
+            if (p.mby >= (int)a.L.mbh) continue;
+            p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;
             memset(s, 0xA5, sizeof *s);   // LDS is not zero-initialised on the device either
-            for (int t = 0; t < RECON_THREADS; t++) recon_phase_load(a, *s, t, tile, pic);
-            for (int t = 0; t < RECON_THREADS; t++) recon_phase_mark(a, *s, t);
-            for (int t = 0; t < RECON_THREADS; t++) recon_phase_compact(a, *s, t);
+            for (int l = 0; l < 64; l++) recon_phase_load(a, *s, l, p);
+            for (int l = 0; l < 64; l++) recon_phase_mark(a, *s, l, p);
+            for (int l = 0; l < 64; l++) recon_phase_compact(a, *s, l);
+            for (int l = 0; l < 64; l++) recon_phase_fetch(a, *s, f[l], l, p);
             const int n_active = recon_n_active(*s);
             for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
-                for (int t = 0; t < RECON_THREADS; t++) recon_phase_idct_rows(a, *s, t, pic, round);
-                for (int t = 0; t < RECON_THREADS; t++) recon_phase_idct_cols(a, *s, t, round);
+                for (int l = 0; l < 64; l++) recon_phase_idct_rows(a, *s, f[l], l, p, round);
+                for (int l = 0; l < 64; l++) recon_phase_idct_cols(a, *s, l, round);
             }
-            for (int t = 0; t < RECON_THREADS; t++) recon_phase_output(a, *s, t, tile, pic);
+            for (int l = 0; l < 64; l++) recon_phase_output(a, *s, f[l], l, p);
         }
+    }
     free(s);
     return 0;
 }
@@ -64,19 +79,29 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
     a.n_pictures = n_pictures;
     a.strength = strength;
     a.tiles_x = (a.L.width + POST_OX + POST_TW - 1) / POST_TW;
-    a.tiles_y = (a.L.height + POST_OY + POST_TH - 1) / POST_TH;
+    a.tiles_y = (post_strips_y(h) + POST_WAVES - 1) / POST_WAVES;
     a.luma_only = luma_only;
-    PostSmem *s = (PostSmem *)aligned_alloc(16, (sizeof(PostSmem) + 15) / 16 * 16);
-    for (uint32_t pic = 0; pic < n_pictures; pic++)
-        for (uint32_t tile = 0; tile < a.tiles_x * a.tiles_y; tile++) {
+    PostStrip *s = (PostStrip *)aligned_alloc(16, (sizeof(PostStrip) + 15) / 16 * 16);
+    // same work decomposition as kernels.hip::k_post: XCD-ordered workgroups, one strip per wave
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * n_pictures, chunk = (total + 7) / 8;
+    static PostFetch pf[64];
+    for (uint32_t wg = 0; wg < chunk * 8; wg++) {
+        const uint32_t xcd = wg & 7, t = wg >> 3, g = xcd * chunk + t;
+        if (t >= chunk || g >= total) continue;
+        const int pic = g / tpp, tile = g % tpp;
+        for (int wave = 0; wave < POST_WAVES; wave++) {
+            const int sx = tile % (int)a.tiles_x, sy = (tile / (int)a.tiles_x) * POST_WAVES + wave;
+            if (sy >= (int)post_strips_y(h)) continue;
             memset(s, 0xA5, sizeof *s);
-            for (int t = 0; t < POST_THREADS; t++) post_phase_load(a, *s, t, tile, pic);
+            for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[l], l, sx, sy, pic);
+            for (int l = 0; l < 64; l++) post_phase_commit(a, *s, pf[l], l);
             if (strength) {
-                for (int t = 0; t < POST_THREADS; t++) post_phase_hedges(a, *s, t, tile);
-                for (int t = 0; t < POST_THREADS; t++) post_phase_vedges(a, *s, t, tile);
+                for (int l = 0; l < 64; l++) post_phase_hedges(a, *s, l, sx, sy);
+                for (int l = 0; l < 64; l++) post_phase_vedges(a, *s, l, sx, sy);
             }
-            for (int t = 0; t < POST_THREADS; t++) post_phase_store(a, *s, t, tile, pic);
+            for (int l = 0; l < 64; l++) post_phase_store(a, *s, l, sx, sy, pic);
         }
+    }
     free(s);
     return 0;
 }

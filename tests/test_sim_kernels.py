@@ -13,7 +13,8 @@ import simlib
 from oracle import oracle as orc
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-SIZES = [(16, 16), (48, 32), (100, 60), (5, 4), (1, 1), (33, 17), (176, 144), (320, 240), (136, 40)]
+SIZES = [(16, 16), (48, 32), (100, 60), (5, 4), (1, 1), (33, 17), (176, 144), (320, 240), (136, 40),
+         (128, 32), (256, 48)]   # the last two: width == row pitch (no padding columns), as at 1920
 
 
 @pytest.mark.parametrize("w,h", SIZES)

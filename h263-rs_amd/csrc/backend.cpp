@@ -58,7 +58,7 @@ struct DeviceGuard {
 uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
 uint32_t recon_tiles_y(const FrameLayout &L) { return (L.mbh + TILE_MBY - 1) / TILE_MBY; }
 uint32_t post_tiles_x(const FrameLayout &L) { return (L.width + POST_OX + POST_TW - 1) / POST_TW; }
-uint32_t post_tiles_y(const FrameLayout &L) { return (post_strips_y(L.height) + POST_WAVES - 1) / POST_WAVES; }
+uint32_t post_tiles_y(const FrameLayout &L) { return (post_strips_y(L.height) + POST_STRIPS - 1) / POST_STRIPS; }
 
 }  // namespace
 

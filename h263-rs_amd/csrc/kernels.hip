@@ -47,11 +47,18 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     WaveFetch f;
     recon_phase_fetch(a, s, f, lane, p);          // every global load of the wave is in flight from here
     const int n_active = recon_n_active(s);
+    // `ln`: the lane index behind an opaque asm, re-derived per phase so that lane-only expressions are
+    // recomputed where they are used instead of being kept in registers across the whole kernel
+    int ln = lane;
+#pragma unroll 1
     for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
-        recon_phase_idct_rows(a, s, f, lane, p, round);
-        recon_phase_idct_cols(a, s, lane, round);
+        asm volatile("" : "+v"(ln));
+        recon_phase_idct_rows(a, s, f, ln, p, round);
+        asm volatile("" : "+v"(ln));
+        recon_phase_idct_cols(a, s, ln, round);
     }
-    recon_phase_output(a, s, f, lane, p);
+    asm volatile("" : "+v"(ln));
+    recon_phase_output(a, s, f, ln, p);
 }
 
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
@@ -82,35 +89,55 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PostStrip &s = strips[wave];
+    // one wave = one 128x32 tile = 4 strips; a workgroup = 4 consecutive tiles of the XCD-ordered list
     const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures;
-    const uint32_t chunk = (total + 7) / 8, xcd = blockIdx.x & 7;
-    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
-    if (t >= chunk || g >= total) return;
+    const uint32_t wgs = (total + POST_WAVES - 1) / POST_WAVES, chunk = (wgs + 7) / 8, xcd = blockIdx.x & 7;
+    const uint32_t t = blockIdx.x >> 3, wg = xcd * chunk + t;
+    if (t >= chunk || wg >= wgs) return;
+    const uint32_t g = wg * POST_WAVES + wave;
+    if (g >= total) return;
     const int pic = (int)(g / tpp), tile = (int)(g % tpp);
-    const int sx = tile % (int)a.tiles_x, sy = (tile / (int)a.tiles_x) * POST_WAVES + wave;
-    if (sy >= (int)post_strips_y(a.L.height)) return;
-    // no workgroup barrier anywhere: the wave owns its strip from load to store
-    PostFetch pf;
-    post_phase_fetch(a, pf, lane, sx, sy, pic);
-    post_phase_commit(a, s, pf, lane);
-    if (a.strength) {
-        post_phase_hedges(a, s, lane, sx, sy);
-        post_phase_vedges(a, s, lane, sx, sy);
+    const int sx = tile % (int)a.tiles_x, sy0 = (tile / (int)a.tiles_x) * POST_STRIPS;
+    // no workgroup barrier anywhere: the wave owns its strips from load to store.  All loads of the
+    // tile are queued first; each strip then waits only for its own.
+    // Two strips are always in flight ahead of the one being filtered.  Strips past the bottom of the
+    // picture are processed like any other (clamped loads, no rows to store), which keeps the code
+    // straight-line and the number of loads fixed, so each wait is an exact s_waitcnt vmcnt(8).
+    PostFetch pf0, pf1;
+    post_phase_fetch(a, pf0, lane, sx, sy0, pic);
+    post_phase_fetch(a, pf1, lane, sx, sy0 + 1, pic);
+#pragma unroll 1
+    for (int k = 0; k < POST_STRIPS; k += 2) {
+        // `ln` is re-derived in every iteration behind an opaque asm, so that lane-only expressions
+        // (LDS offsets, column indices, ...) are recomputed where used instead of being hoisted out of
+        // the loop and pinned in registers for its whole length: recomputing is a few cheap VALU ops,
+        // while the hoisted form cost half of the occupancy.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        post_phase_commit(a, s, pf0, ln);
+        post_phase_fetch(a, pf0, ln, sx, sy0 + k + 2, pic);
+        if (a.strength) {
+            post_phase_hedges(a, s, ln, sx, sy0 + k);
+            post_phase_vedges(a, s, ln, sx, sy0 + k);
+        }
+        post_phase_store(a, s, ln, sx, sy0 + k, pic);
+
+        asm volatile("" : "+v"(ln));
+        post_phase_commit(a, s, pf1, ln);
+        post_phase_fetch(a, pf1, ln, sx, sy0 + k + 3, pic);
+        if (a.strength) {
+            post_phase_hedges(a, s, ln, sx, sy0 + k + 1);
+            post_phase_vedges(a, s, ln, sx, sy0 + k + 1);
+        }
+        post_phase_store(a, s, ln, sx, sy0 + k + 1, pic);
     }
-    post_phase_store(a, s, lane, sx, sy, pic);
 }
 
 hipError_t launch_post(const PostArgs &args, hipStream_t stream)
 {
-    static const uint32_t env_debug = [] {
-        const char *e = getenv("H263MI_DEBUG_POST");
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    PostArgs a = args;
-    a.debug_flags |= env_debug;
     const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures;
-    const uint32_t chunk = (total + 7) / 8;
-    hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, a);
+    const uint32_t wgs = (total + POST_WAVES - 1) / POST_WAVES, chunk = (wgs + 7) / 8;
+    hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, args);
     return hipGetLastError();
 }
 

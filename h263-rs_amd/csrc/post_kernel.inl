@@ -30,6 +30,7 @@ constexpr int POST_SH = 8;                          // luma rows per strip (one 
 constexpr int POST_CW = 64, POST_CSH = 4;           // chroma strip
 constexpr int POST_OX = POST_TW - 4;                // strip column sx starts at sx*128 - 124
 constexpr int POST_WAVES = POST_THREADS / 64;
+constexpr int POST_STRIPS = 4;                      // strips (vertical neighbours) per wave = one 128x32 tile
 
 struct PostStrip {
     uint8_t y[POST_SH * POST_TW];
@@ -61,67 +62,45 @@ H263_HD void deblock_quartet(int &A, int &B, int &C, int &D, int strength, bool 
     D = (D + d2) & 0xff;
 }
 
-// bt601.rs:12-59, one pixel -> packed R | G<<8 | B<<16 | 255<<24
-H263_HD uint32_t bt601_pixel(int y, int cb, int cr)
-{
-    const int gray = (y - 16) * 76309 + 32768;
-    const int r = gray + (cr - 128) * 104597;
-    const int g = gray + (cr - 128) * -53279 + (cb - 128) * -25675;
-    const int b = gray + (cb - 128) * 132201;
-    // clamp(v >> 16, 0, 255) == clamp(v, 0, 0xFFFFFF) >> 16 (the shift is monotone).  Written in
-    // this order on purpose: hipcc (ROCm 7.2) turns the shift-then-clamp form into the gfx950
-    // instruction v_ashr_pk_u8_i32, whose result for negative inputs did not match the 0 the
-    // reference expects (caught by the bt601.rs:206-207 golden on an MI355X).
-    const uint32_t R = (uint32_t)clampi(r, 0, 0xFFFFFF) >> 16;
-    const uint32_t G = (uint32_t)clampi(g, 0, 0xFFFFFF) >> 16;
-    const uint32_t B = (uint32_t)clampi(b, 0, 0xFFFFFF) >> 16;
-    return R | (G << 8) | (B << 16) | 0xff000000u;
-}
-
 // ---- phase 0: strip -> registers -> LDS -----------------------------------------------------
 struct PostFetch {
     uint32_t y[4];
-    uint16_t c[4];
+    uint32_t c[4];     // one 16-bit pair each, kept unpacked so that nothing touches them before the commit
 };
 
-// lane = 16 luma bytes (row = lane/8) and 8 chroma bytes (plane = lane/32, row = (lane/8)%4)
+// lane = 16 luma bytes (row = lane/8) and 8 chroma bytes (plane = lane/32, row = (lane/8)%4).
+// Every load is issued unconditionally from a clamped address (bytes outside the picture are never
+// used), so the number of loads per strip is fixed: a wave queues the loads of several strips up
+// front and the wait in front of each strip leaves the later ones in flight (s_waitcnt vmcnt(N)).
 H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx, int sy, int pic)
 {
     const uint8_t *frame = a.frames + (size_t)pic * a.L.frame_bytes;
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
-    if (a.debug_flags & 1) {                                  // diagnosis: compute and stores without the loads
+#if defined(H263MI_DIAG_POST_NO_LOADS)                        // diagnosis build: compute and stores without the loads
 #pragma unroll
-        for (int q = 0; q < 4; q++) { r.y[q] = 0x40506070u + lane + sy; r.c[q] = (uint16_t)(0x8070 + lane); }
-        return;
-    }
+    for (int q = 0; q < 4; q++) { r.y[q] = 0x40506070u + lane + sy; r.c[q] = (uint16_t)(0x8070 + lane); }
+    return;
+#endif
     {
         const int row = lane >> 3, col = (lane & 7) * 16;
-        const int gy = yl + row;
+        const uint32_t gy = (uint32_t)clampi(yl + row, 0, (int)a.L.rows_y - 1);
+        const uint8_t *src = frame + gy * a.L.pitch_y;
 #pragma unroll
-        for (int q = 0; q < 4; q++) r.y[q] = 0;
-        if (gy >= 0 && gy < (int)a.L.rows_y) {
-            const uint8_t *src = frame + (size_t)gy * a.L.pitch_y;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int gx = xl + col + 4 * q;
-                if (gx >= 0 && gx + 4 <= (int)a.L.pitch_y) r.y[q] = *reinterpret_cast<const uint32_t *>(src + gx);
-            }
+        for (int q = 0; q < 4; q++) {
+            const int gx = clampi(xl + col + 4 * q, 0, (int)a.L.pitch_y - 4);
+            r.y[q] = *reinterpret_cast<const uint32_t *>(src + gx);
         }
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) r.c[q] = 0;
-    if (a.luma_only) return;
     {
+        // (a luma-only call has no chroma planes: the loads still run, from the luma plane, and are ignored)
         const int plane = lane >> 5, row = (lane >> 3) & 3, col = (lane & 7) * 8;
         const int cxl = xl / 2, cyl = yl / 2;                 // xl, yl are even (and may be negative)
-        const int gy = cyl + row;
-        const uint8_t *src = frame + (plane ? a.L.off_cr : a.L.off_cb) + (size_t)(gy < 0 ? 0 : gy) * a.L.pitch_c;
-        if (gy >= 0 && gy < (int)a.L.rows_c) {
+        const uint32_t gy = (uint32_t)clampi(cyl + row, 0, (int)a.L.rows_c - 1);
+        const uint8_t *src = frame + (a.luma_only ? 0u : (plane ? a.L.off_cr : a.L.off_cb)) + gy * a.L.pitch_c;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int gx = cxl + col + 2 * q;
-                if (gx >= 0 && gx + 2 <= (int)a.L.pitch_c) r.c[q] = *reinterpret_cast<const uint16_t *>(src + gx);
-            }
+        for (int q = 0; q < 4; q++) {
+            const int gx = clampi(cxl + col + 2 * q, 0, (int)a.L.pitch_c - 2);
+            r.c[q] = *reinterpret_cast<const uint16_t *>(src + gx);
         }
     }
 }
@@ -135,7 +114,7 @@ H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch
     if (a.luma_only) return;
     {
         const int plane = lane >> 5, row = (lane >> 3) & 3, col = (lane & 7) * 8;
-        uint64_t packed = (uint64_t)r.c[0] | ((uint64_t)r.c[1] << 16) | ((uint64_t)r.c[2] << 32) | ((uint64_t)r.c[3] << 48);
+        uint64_t packed = (uint64_t)(r.c[0] & 0xffff) | ((uint64_t)(r.c[1] & 0xffff) << 16) | ((uint64_t)(r.c[2] & 0xffff) << 32) | ((uint64_t)r.c[3] << 48);
         *reinterpret_cast<uint64_t *>(&s.c[plane][row * POST_CW + col]) = packed;
     }
 }
@@ -218,6 +197,42 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
 }
 
 // ---- phase 3: BT.601 -> RGBA, optional filtered planes -------------------------------------
+// bt601.rs:25-58 regrouped so that everything that depends only on the chroma sample is computed
+// once per 2x2 quad:  R = (Y*76309 + [Cr*104597 + K]) >> 16, etc., K = 32768 - 16*76309 - 128*coef.
+// The sums are identical integers to the reference's (gray + cr2r + half), only associated differently.
+struct ChromaTerms {
+    int r, g, b;
+};
+H263_HD ChromaTerms bt601_chroma_terms(int cb, int cr)
+{
+    const int K = 32768 - 16 * 76309;
+    ChromaTerms t;
+    t.r = cr * 104597 + (K - 128 * 104597);
+    t.g = cr * -53279 + cb * -25675 + (K + 128 * 53279 + 128 * 25675);
+    t.b = cb * 132201 + (K - 128 * 132201);
+    return t;
+}
+
+// clamp(v >> 16, 0, 255) for three channels, packed as R | G<<8 | B<<16 | 255<<24
+H263_DEV uint32_t bt601_pack(int r, int g, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_ashr_pk_u8_i32 does shift + saturate + pack for two values; only bits 15:0 of its result are
+    // defined (tools/probes/probe_ashr_pk.hip), so the halves are merged with a byte permute.
+    uint32_t rg, ba;
+    const int alpha = 255 << 16;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(rg) : "v"(r), "v"(g));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(ba) : "v"(b), "v"(alpha));
+    return __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+#else
+    // clamp(v >> 16, 0, 255) == clamp(v, 0, 0xFFFFFF) >> 16 (the shift is monotone)
+    const uint32_t R = (uint32_t)clampi(r, 0, 0xFFFFFF) >> 16;
+    const uint32_t G = (uint32_t)clampi(g, 0, 0xFFFFFF) >> 16;
+    const uint32_t B = (uint32_t)clampi(b, 0, 0xFFFFFF) >> 16;
+    return R | (G << 8) | (B << 16) | 0xff000000u;
+#endif
+}
+
 H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx, int sy, int pic)
 {
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
@@ -225,26 +240,34 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
 
     if (a.rgba) {
         uint8_t *rgba = a.rgba + (size_t)pic * w * h * 4;
+        const int g = lane & 31, gx = xl + 4 * g;
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            // 32 consecutive lanes write 512 contiguous bytes of one RGBA row
-            const int item = it * 64 + lane, row = item >> 5, g = item & 31;
-            const int gy = yl + row, gx = xl + 4 * g;
-            if (gy < 0 || gy >= h || gx < 0 || gx >= w) continue;
-            const uint32_t yv = *reinterpret_cast<const uint32_t *>(&s.y[row * POST_TW + 4 * g]);
-            // nearest-neighbour chroma: pixel x uses sample x/2 of row y/2 (bt601.rs:96-98)
-            const uint32_t cbv = *reinterpret_cast<const uint16_t *>(&s.c[0][(row >> 1) * POST_CW + 2 * g]);
-            const uint32_t crv = *reinterpret_cast<const uint16_t *>(&s.c[1][(row >> 1) * POST_CW + 2 * g]);
-            uint32_t px[4];
+        for (int it = 0; it < 2; it++) {
+            // a lane converts a 4x2 block: two rows that share one chroma row (nearest-neighbour
+            // chroma, bt601.rs:96-98); 32 consecutive lanes write 512 contiguous bytes of a row
+            const int q = (lane >> 5) + 2 * it;                  // chroma row of the strip, 0..3
+            const uint32_t cbv = *reinterpret_cast<const uint16_t *>(&s.c[0][q * POST_CW + 2 * g]);
+            const uint32_t crv = *reinterpret_cast<const uint16_t *>(&s.c[1][q * POST_CW + 2 * g]);
+            const ChromaTerms t0 = bt601_chroma_terms(cbv & 0xff, crv & 0xff);
+            const ChromaTerms t1 = bt601_chroma_terms(cbv >> 8, crv >> 8);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                px[k] = bt601_pixel((yv >> (8 * k)) & 0xff, (cbv >> (8 * (k >> 1))) & 0xff, (crv >> (8 * (k >> 1))) & 0xff);
-            uint8_t *dst = rgba + ((size_t)gy * w + gx) * 4;
-            if ((a.debug_flags & 2) && px[0] != 0x12345678u) continue;   // diagnosis: loads and compute without the stores
-            if (gx + 4 <= w && (w & 3) == 0) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
-            } else {
-                for (int k = 0; k < 4 && gx + k < w; k++) memcpy(dst + 4 * k, &px[k], 4);
+            for (int rr = 0; rr < 2; rr++) {
+                const int row = 2 * q + rr, gy = yl + row;
+                if (gy < 0 || gy >= h || gx < 0 || gx >= w) continue;
+                const uint32_t yv = *reinterpret_cast<const uint32_t *>(&s.y[row * POST_TW + 4 * g]);
+                uint32_t px[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int gray = (int)((yv >> (8 * k)) & 0xff) * 76309;
+                    const ChromaTerms &t = (k < 2) ? t0 : t1;
+                    px[k] = bt601_pack(gray + t.r, gray + t.g, gray + t.b);
+                }
+                uint8_t *dst = rgba + ((size_t)gy * w + gx) * 4;
+                if (gx + 4 <= w && (w & 3) == 0) {
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+                } else {
+                    for (int k = 0; k < 4 && gx + k < w; k++) memcpy(dst + 4 * k, &px[k], 4);
+                }
             }
         }
     }

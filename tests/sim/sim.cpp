@@ -79,27 +79,35 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
     a.n_pictures = n_pictures;
     a.strength = strength;
     a.tiles_x = (a.L.width + POST_OX + POST_TW - 1) / POST_TW;
-    a.tiles_y = (post_strips_y(h) + POST_WAVES - 1) / POST_WAVES;
+    a.tiles_y = (post_strips_y(h) + POST_STRIPS - 1) / POST_STRIPS;
     a.luma_only = luma_only;
     PostStrip *s = (PostStrip *)aligned_alloc(16, (sizeof(PostStrip) + 15) / 16 * 16);
-    // same work decomposition as kernels.hip::k_post: XCD-ordered workgroups, one strip per wave
-    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * n_pictures, chunk = (total + 7) / 8;
-    static PostFetch pf[64];
-    for (uint32_t wg = 0; wg < chunk * 8; wg++) {
-        const uint32_t xcd = wg & 7, t = wg >> 3, g = xcd * chunk + t;
-        if (t >= chunk || g >= total) continue;
-        const int pic = g / tpp, tile = g % tpp;
+    // same work decomposition as kernels.hip::k_post: XCD-ordered workgroups of 4 waves, one tile
+    // (4 strips) per wave, all loads of the tile first
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * n_pictures;
+    const uint32_t wgs = (total + POST_WAVES - 1) / POST_WAVES, chunk = (wgs + 7) / 8;
+    static PostFetch pf[POST_STRIPS][64];
+    for (uint32_t b = 0; b < chunk * 8; b++) {
+        const uint32_t xcd = b & 7, t = b >> 3, wg = xcd * chunk + t;
+        if (t >= chunk || wg >= wgs) continue;
         for (int wave = 0; wave < POST_WAVES; wave++) {
-            const int sx = tile % (int)a.tiles_x, sy = (tile / (int)a.tiles_x) * POST_WAVES + wave;
-            if (sy >= (int)post_strips_y(h)) continue;
-            memset(s, 0xA5, sizeof *s);
-            for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[l], l, sx, sy, pic);
-            for (int l = 0; l < 64; l++) post_phase_commit(a, *s, pf[l], l);
-            if (strength) {
-                for (int l = 0; l < 64; l++) post_phase_hedges(a, *s, l, sx, sy);
-                for (int l = 0; l < 64; l++) post_phase_vedges(a, *s, l, sx, sy);
+            const uint32_t g = wg * POST_WAVES + wave;
+            if (g >= total) continue;
+            const int pic = g / tpp, tile = g % tpp;
+            const int sx = tile % (int)a.tiles_x, sy0 = (tile / (int)a.tiles_x) * POST_STRIPS;
+            for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[0][l], l, sx, sy0, pic);
+            for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[1][l], l, sx, sy0 + 1, pic);
+            for (int k = 0; k < POST_STRIPS; k++) {
+                const int sy = sy0 + k;      // strips past the bottom run too (nothing to store), as on the device
+                memset(s, 0xA5, sizeof *s);
+                for (int l = 0; l < 64; l++) post_phase_commit(a, *s, pf[k & 1][l], l);
+                for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[k & 1][l], l, sx, sy + 2, pic);
+                if (strength) {
+                    for (int l = 0; l < 64; l++) post_phase_hedges(a, *s, l, sx, sy);
+                    for (int l = 0; l < 64; l++) post_phase_vedges(a, *s, l, sx, sy);
+                }
+                for (int l = 0; l < 64; l++) post_phase_store(a, *s, l, sx, sy, pic);
             }
-            for (int l = 0; l < 64; l++) post_phase_store(a, *s, l, sx, sy, pic);
         }
     }
     free(s);

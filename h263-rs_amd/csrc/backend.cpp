@@ -7,6 +7,7 @@
 #include <new>
 #include <vector>
 
+#include "../host/bitstream.hpp"
 #include "kernels.h"
 #include "post_kernel.inl"   // tile constants only
 #include "recon_kernel.inl"  // tile constants only
@@ -524,9 +525,34 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, cons
 
 int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len, size_t *consumed)
 {
-    (void)data; (void)len; (void)consumed;
-    if (!s) return H263MI_ERR_INVALID_ARGUMENT;
-    return H263MI_ERR_UNIMPLEMENTED_DECODING;   // host bitstream parser: SURVEY section 8 row f-1
+    if (!s || (!data && len)) return H263MI_ERR_INVALID_ARGUMENT;
+    if (consumed) *consumed = 0;
+    // serial half on the host (state.rs:143-427) ...
+    bits::ParsedPicture pic;
+    RC_TRY(bits::parse_picture(data, len, s->options, pic));
+    // ... everything from the cut line on (state.rs:421-483) on the GPU.  Nothing has touched the state so
+    // far, so every error above leaves it unchanged, like the reader transaction of state.rs:142.
+    RC_TRY(h263mi_submit_picture(s, &pic.desc, pic.mbs.data(), pic.mbs.size(), pic.coeffs.data(), pic.coeffs.size() / 64));
+    if (consumed) *consumed = pic.bits_consumed / 8;     // reader.commit() drains whole bytes (reader.rs:391-394)
+    return H263MI_OK;
+}
+
+int h263mi_parse_picture_header(const h263mi_state *s, const uint8_t *data, size_t len, h263mi_picture_desc *out)
+{
+    if (!s || !out || (!data && len)) return H263MI_ERR_INVALID_ARGUMENT;
+    bits::BitReader r(data, len);
+    bits::PictureHeader h;
+    bool is_picture = false;
+    RC_TRY(bits::decode_picture_header(r, s->options, h, is_picture));
+    if (!is_picture) return H263MI_ERR_MIDDLE_OF_BITSTREAM;
+    memset(out, 0, sizeof *out);
+    out->width = h.width;
+    out->height = h.height;
+    out->picture_type = h.picture_type;
+    out->pquant = h.quantizer;
+    out->use_deblocker = h.use_deblocker ? 1 : 0;
+    out->temporal_reference = h.temporal_reference;
+    return H263MI_OK;
 }
 
 static int fill_view(const h263mi_state *s, h263mi_frame_view *out)

@@ -40,6 +40,7 @@ EXPORTS = [
     "h263mi_strerror", "h263mi_abi_version",
     "h263mi_state_new", "h263mi_state_free", "h263mi_state_is_sorenson", "h263mi_state_reset",
     "h263mi_state_cleanup_buffers", "h263mi_submit_picture", "h263mi_decode_next_picture",
+    "h263mi_parse_picture_header",
     "h263mi_get_last_picture", "h263mi_get_reference_picture", "h263mi_copy_yuv", "h263mi_render_rgba",
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
@@ -111,6 +112,7 @@ def lib():
         L.h263mi_state_cleanup_buffers.argtypes = [vp]
         L.h263mi_submit_picture.argtypes = [vp, C.POINTER(PictureDesc), vp, sz, vp, sz]
         L.h263mi_decode_next_picture.argtypes = [vp, vp, sz, C.POINTER(sz)]
+        L.h263mi_parse_picture_header.argtypes = [vp, vp, sz, C.POINTER(PictureDesc)]
         L.h263mi_get_last_picture.argtypes = [vp, C.POINTER(FrameView)]
         L.h263mi_get_reference_picture.argtypes = [vp, C.POINTER(FrameView)]
         L.h263mi_copy_yuv.argtypes = [vp, vp, vp, vp]
@@ -259,6 +261,13 @@ class H263State:
         used = C.c_size_t(0)
         _check(lib().h263mi_decode_next_picture(self._h, _p(data), data.size, C.byref(used)), "decode_next_picture")
         return used.value
+
+    def parse_picture(self, data):
+        """H263State::parse_picture (state.rs:102-111): header fields of the picture that starts `data`."""
+        data = np.frombuffer(bytes(data), dtype=np.uint8)
+        d = PictureDesc()
+        _check(lib().h263mi_parse_picture_header(self._h, _p(data), data.size, C.byref(d)), "parse_picture")
+        return d
 
     def _view(self, fn, what):
         v = FrameView()

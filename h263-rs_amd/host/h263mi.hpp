@@ -98,6 +98,14 @@ public:
         return used;
     }
 
+    // H263State::parse_picture (state.rs:102-111): header peek
+    h263mi_picture_desc parse_picture(const uint8_t *data, size_t len) const
+    {
+        h263mi_picture_desc d{};
+        check(h263mi_parse_picture_header(s_, data, len, &d));
+        return d;
+    }
+
     // record-level form of decode_next_picture (state.rs:421-483): what the host parser hands over
     void submit_picture(const h263mi_picture_desc &desc, const std::vector<h263mi_mb_record> &mbs,
                         const std::vector<int16_t> &coeffs)

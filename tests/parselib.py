@@ -1,0 +1,77 @@
+"""ctypes access to the CPU-only build of the host bitstream parser (tests/parser)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from oracle.oracle import MB_RECORD_DTYPE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+TCOEF, MCBPC_I, MCBPC_P, CBPY, MVD = range(5)
+EOF_ERR = -16
+
+
+class PictureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("picture_type", C.c_uint8), ("pquant", C.c_uint8),
+                ("use_deblocker", C.c_uint8), ("reserved0", C.c_uint8), ("temporal_reference", C.c_uint16),
+                ("reserved1", C.c_uint16)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "parser"), "-s"])
+        L = C.CDLL(os.path.join(HERE, "parser", "libh263parse_test.so"))
+        L.pt_read_vlc.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.pt_decode_block.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.POINTER(C.c_size_t)]
+        L.pt_reader_script.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.pt_reader_script.restype = None
+        L.pt_parse_picture.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(PictureDesc), C.c_void_p,
+                                       C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _lib = L
+    return _lib
+
+
+def _bytes(data):
+    a = np.frombuffer(bytes(bytearray(data)), dtype=np.uint8).copy()
+    return a if a.size else np.zeros(1, np.uint8), len(data)
+
+
+def read_vlc(table, data, n):
+    a, ln = _bytes(data)
+    out = np.zeros((n, 4), np.int32)
+    k = lib().pt_read_vlc(table, a.ctypes.data, ln, n, out.ctypes.data)
+    return out[:k]
+
+
+def decode_block(data, sorenson, version, intra, tcoef_present):
+    a, ln = _bytes(data)
+    out = np.zeros(4 + 3 * 80, np.int32)
+    used = C.c_size_t()
+    rc = lib().pt_decode_block(a.ctypes.data, ln, int(sorenson), -1 if version is None else version, int(intra),
+                               int(tcoef_present), out.ctypes.data, C.byref(used))
+    n = int(out[3])
+    return rc, bool(out[1]), int(out[2]), [tuple(int(v) for v in out[4 + 3 * i:7 + 3 * i]) for i in range(n)], used.value
+
+
+def reader_script(data, ops):
+    a, ln = _bytes(data)
+    o = np.array(ops, np.int32).reshape(-1, 2)
+    res = np.zeros((len(o), 2), np.int64)
+    lib().pt_reader_script(a.ctypes.data, ln, len(o), o.ctypes.data, res.ctypes.data)
+    return [(int(r), int(v)) for r, v in res]
+
+
+def parse_picture(data, options=1, cap_mbs=20000, cap_blocks=120000):
+    a, ln = _bytes(data)
+    d = PictureDesc()
+    mbs = np.zeros(cap_mbs, MB_RECORD_DTYPE)
+    co = np.zeros((cap_blocks, 64), np.int16)
+    n_mbs, n_blocks, bits = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    rc = lib().pt_parse_picture(a.ctypes.data, ln, options, C.byref(d), mbs.ctypes.data, cap_mbs, co.ctypes.data,
+                                cap_blocks, C.byref(n_mbs), C.byref(n_blocks), C.byref(bits))
+    return rc, d, mbs[:n_mbs.value].copy(), co[:n_blocks.value].copy(), bits.value

@@ -1,0 +1,79 @@
+// parser_shim.cpp -- C entry points over h263-rs_amd/host/bitstream.{hpp,cpp} for the CPU-only parser
+// tests (tests/test_parser.py).  Test infrastructure: the product reaches the parser through
+// h263mi_decode_next_picture only.
+#include <cstring>
+
+#include "../../h263-rs_amd/host/bitstream.hpp"
+
+using namespace h263mi::bits;
+
+extern "C" {
+
+// table: 0 TCOEF, 1 MCBPC-I, 2 MCBPC-P, 3 CBPY, 4 MVD.  out[i] = {status, v0, v1, v2}; status 1 valid, 0 invalid
+// code, negative = error code (EOF).  Returns the number of entries written.
+int pt_read_vlc(int table, const uint8_t *data, size_t len, int n, int32_t *out)
+{
+    const VlcTable *t = table == 0 ? &tcoef_table() : table == 1 ? &mcbpc_i_table() : table == 2 ? &mcbpc_p_table()
+                        : table == 3 ? &cbpy_table() : &mvd_table();
+    BitReader r(data, len);
+    int i = 0;
+    for (; i < n; i++) {
+        VlcHit h{};
+        int rc = t->decode(r, h);
+        out[4 * i + 0] = rc != H263MI_OK ? rc : (h.valid ? 1 : 0);
+        out[4 * i + 1] = h.v0; out[4 * i + 2] = h.v1; out[4 * i + 3] = h.v2;
+        if (rc != H263MI_OK) { i++; break; }
+    }
+    return i;
+}
+
+// decode_block; out: [rc, has_intradc, intradc_code, n_tcoef, then (is_short, run, level) triples]
+int pt_decode_block(const uint8_t *data, size_t len, int sorenson, int version, int intra, int tcoef_present,
+                    int32_t *out, size_t *bits_used)
+{
+    BitReader r(data, len);
+    ParsedBlock b;
+    int rc = decode_block(r, sorenson != 0, version, intra != 0, tcoef_present != 0, b);
+    out[0] = rc; out[1] = b.has_intradc; out[2] = b.intradc; out[3] = b.n_tcoef;
+    for (int i = 0; i < b.n_tcoef; i++) {
+        out[4 + 3 * i] = b.tcoef[i].is_short; out[5 + 3 * i] = b.tcoef[i].run; out[6 + 3 * i] = b.tcoef[i].level;
+    }
+    *bits_used = r.position();
+    return rc;
+}
+
+// a small script interpreter over BitReader for the reader.rs tests:
+// ops: 0 read_bits(n) 1 peek_bits(n) 2 skip_bits(n) 3 read_signed_bits(n) 4 recognize_start_code(in_error = n)
+// result[i] = {rc, value}
+void pt_reader_script(const uint8_t *data, size_t len, int n_ops, const int32_t *ops, int64_t *result)
+{
+    BitReader r(data, len);
+    for (int i = 0; i < n_ops; i++) {
+        const int op = ops[2 * i], arg = ops[2 * i + 1];
+        uint32_t u = 0; int32_t s = 0; int sk = 0; int rc = 0; int64_t val = 0;
+        switch (op) {
+        case 0: rc = r.read_bits((uint32_t)arg, u); val = u; break;
+        case 1: rc = r.peek_bits((uint32_t)arg, u); val = u; break;
+        case 2: rc = r.skip_bits((uint32_t)arg); break;
+        case 3: rc = r.read_signed_bits((uint32_t)arg, s); val = s; break;
+        default: rc = r.recognize_start_code(arg != 0, sk); val = sk; break;
+        }
+        result[2 * i] = rc; result[2 * i + 1] = val;
+    }
+}
+
+// whole picture -> records.  Returns rc; *n_mbs / *n_blocks the counts (capacity checked).
+int pt_parse_picture(const uint8_t *data, size_t len, uint32_t options, h263mi_picture_desc *desc, h263mi_mb_record *mbs,
+                     size_t cap_mbs, int16_t *coeffs, size_t cap_blocks, size_t *n_mbs, size_t *n_blocks, size_t *bits)
+{
+    ParsedPicture p;
+    int rc = parse_picture(data, len, options, p);
+    *n_mbs = p.mbs.size(); *n_blocks = p.coeffs.size() / 64; *bits = p.bits_consumed;
+    if (rc != H263MI_OK) return rc;
+    *desc = p.desc;
+    if (p.mbs.size() > cap_mbs || p.coeffs.size() / 64 > cap_blocks) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!p.mbs.empty()) memcpy(mbs, p.mbs.data(), p.mbs.size() * sizeof(h263mi_mb_record));
+    if (!p.coeffs.empty()) memcpy(coeffs, p.coeffs.data(), p.coeffs.size() * sizeof(int16_t));
+    return rc;
+}
+}

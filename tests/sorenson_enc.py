@@ -1,0 +1,193 @@
+"""A tiny Sorenson Spark (H.263 flavour of FLV1, version 1) bitstream WRITER for fixtures.
+
+Test infrastructure: the reference ships no sample streams, so end-to-end tests of
+decode_next_picture(bytes) need pictures serialised from known macroblock records.  The layout follows
+the reference's parser: picture header (parser/picture.rs:619-659), macroblock layer
+(parser/macroblock.rs:445-549), block layer (parser/block.rs:670-755); motion vectors are coded as
+differences against the median predictor of decoder/cpu/mvd_pred.rs:27-67.  The code tables are the ones in
+h263-rs_amd/host/vlc_tables.inc, which tests/test_parser.py checks against the reference's golden vectors.
+"""
+import os
+import re
+
+import numpy as np
+
+from oracle.np_restatement import ZIGZAG_RASTER
+
+_INC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "h263-rs_amd", "host", "vlc_tables.inc")
+
+
+def _load_tables():
+    tables, cur = {}, None
+    for line in open(_INC):
+        m = re.match(r"static const VlcCode (\w+)\[\]", line)
+        if m:
+            cur = tables.setdefault(m.group(1), [])
+            continue
+        m = re.match(r'\s*\{"([01]+)",\s*(-?\d+),\s*(-?\d+),\s*(-?\d+)\}', line)
+        if m and cur is not None:
+            cur.append((m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))))
+    return tables
+
+
+_T = _load_tables()
+TCOEF = {(v0, v1, v2): c for c, v0, v1, v2 in _T["kTcoefCodes"] if v0 >= 0}
+TCOEF_ESCAPE = [c for c, v0, _, _ in _T["kTcoefCodes"] if v0 < 0][0]
+MCBPC_I = {(v0, v1, v2): c for c, v0, v1, v2 in _T["kMcbpcICodes"] if v0 >= 0}
+MCBPC_P = {(v0, v1, v2): c for c, v0, v1, v2 in _T["kMcbpcPCodes"] if v0 >= 0}
+STUFFING = [c for c, v0, _, _ in _T["kMcbpcPCodes"] if v0 < 0][0]
+CBPY = {v0: c for c, v0, _, _ in _T["kCbpyCodes"]}
+MVD = {v0: c for c, v0, _, _ in _T["kMvdCodes"]}
+DQUANT_CODE = {-1: "00", -2: "01", 1: "10", 2: "11"}
+FORMATS = {(352, 288): 2, (176, 144): 3, (128, 96): 4, (320, 240): 5, (160, 120): 6}
+
+
+class BitWriter:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, value, n):
+        self.bits.append(format(value & ((1 << n) - 1), "0%db" % n) if n else "")
+
+    def code(self, s):
+        self.bits.append(s)
+
+    def tobytes(self, pad_to_byte=True):
+        s = "".join(self.bits)
+        if pad_to_byte and len(s) % 8:
+            s += "0" * (8 - len(s) % 8)
+        return bytes(int(s[i:i + 8], 2) for i in range(0, len(s), 8))
+
+
+def _median(a, b, c):
+    return sorted((a, b, c))[1]
+
+
+def predict(pv, cur, mbw, index):
+    """mvd_pred.rs:27-67 (pv: list of [4][2] for the macroblocks coded so far)."""
+    n, col = len(pv), len(pv) % mbw
+    z = (0, 0)
+    mv1 = (z if col == 0 else tuple(pv[n - 1][index + 1])) if index in (0, 2) else tuple(cur[index - 1])
+    line = n // mbw
+    last_line = max(line - 1, 0) * mbw + col
+    if index <= 1:
+        mv2 = mv1 if line == 0 else tuple(pv[last_line][index + 2])
+        mv3 = z if col == mbw - 1 else (mv1 if line == 0 else tuple(pv[last_line + 1][2]))
+    else:
+        mv2, mv3 = tuple(cur[0]), tuple(cur[1])
+    return (_median(mv1[0], mv2[0], mv3[0]), _median(mv1[1], mv2[1], mv3[1]))
+
+
+def mvd_for(mv, pred):
+    """difference d in [-32, 31] that halfpel_decode (mvd_pred.rs:70-117) maps back to mv (mv in [-32, 31])."""
+    assert -32 <= mv <= 31, mv
+    d = mv - pred
+    if d < -32:
+        d += 64
+    elif d > 31:
+        d -= 64
+    out = d + pred                       # what the decoder computes first
+    if not (-32 <= out < 32):
+        inv = d - 64 if d > 0 else (d + 64 if d < 0 else d)
+        out = inv + pred
+    assert out == mv, (mv, pred, d, out)
+    return d
+
+
+def write_block(bw, coeff, intra, intradc, coded, extra_events=()):
+    if intra:
+        bw.put(int(intradc), 8)
+    if not coded:
+        return
+    events, last = [], 1 if intra else 0
+    for z in range(last, 64):
+        lv = int(coeff[ZIGZAG_RASTER[z]])
+        if lv:
+            events.append((z - last, lv))
+            last = z + 1
+    events += list(extra_events)          # e.g. a run that walks past zigzag 63 (rle.rs:125-127)
+    assert events, "a coded block needs at least one TCOEF"
+    for i, (run, lv) in enumerate(events):
+        is_last = 1 if i == len(events) - 1 else 0
+        key = (is_last, run, abs(lv))
+        if key in TCOEF:
+            bw.code(TCOEF[key])
+            bw.put(1 if lv < 0 else 0, 1)
+        else:
+            bw.code(TCOEF_ESCAPE)
+            if -64 <= lv <= 63:
+                bw.put(0, 1); bw.put(is_last, 1); bw.put(run, 6); bw.put(lv, 7)
+            else:
+                assert -1024 <= lv <= 1023
+                bw.put(1, 1); bw.put(is_last, 1); bw.put(run, 6); bw.put(lv, 11)
+
+
+def encode_picture(width, height, picture_type, pquant, mbs, coeffs, temporal_reference=0, deblock_flag=0,
+                   version=1, uncoded_as_cod=True, stuffing_every=0, overflow_blocks=()):
+    """records (mb_type, quant, cbp, mv, intradc, coeff_index) + coefficient blocks -> bytes.
+
+    The quantiser of each coded macroblock must be reachable from the previous one by a DQUANT of
+    {-2,-1,0,1,2}; Q types are chosen automatically.  overflow_blocks: set of (mb, blk) whose coded block gets an
+    extra event with run 63, i.e. the `kill` path."""
+    bw = BitWriter()
+    bw.put(1, 17)                                     # start code
+    bw.put(version, 5)
+    bw.put(temporal_reference, 8)
+    if (width, height) in FORMATS:
+        bw.put(FORMATS[(width, height)], 3)
+    elif width < 256 and height < 256:
+        bw.put(0, 3); bw.put(width, 8); bw.put(height, 8)
+    else:
+        bw.put(1, 3); bw.put(width, 16); bw.put(height, 16)
+    bw.put(picture_type, 2)
+    bw.put(deblock_flag, 1)
+    bw.put(pquant, 5)
+    bw.put(0, 1)                                      # PEI
+    mbw = (width + 15) // 16
+    quant = pquant
+    pv = []
+    coeffs = np.asarray(coeffs, np.int16).reshape(-1, 64)
+    for i, m in enumerate(mbs):
+        if stuffing_every and i % stuffing_every == 0:
+            if picture_type != 0:
+                bw.put(0, 1)
+            bw.code(STUFFING)
+        t, cbp = int(m["mb_type"]), int(m["cbp"])
+        intra = t in (3, 4)
+        mv = np.asarray(m["mv"], np.int64)
+        if picture_type != 0:
+            if (not intra) and cbp == 0 and not mv.any() and uncoded_as_cod and int(m["quant"]) == quant and t == 0:
+                bw.put(1, 1)                          # COD = 1: not coded
+                pv.append([[0, 0]] * 4)
+                continue
+            bw.put(0, 1)
+        dq = int(m["quant"]) - quant
+        assert -2 <= dq <= 2, "quantiser step not codable"
+        four = t in (2, 5)
+        t = (4 if dq else 3) if intra else ((5 if dq else 2) if four else (1 if dq else 0))
+        cb, cr = (cbp >> 4) & 1, (cbp >> 5) & 1
+        bw.code((MCBPC_I if picture_type == 0 else MCBPC_P)[(t, cb, cr)])
+        luma = ((cbp & 1) << 3) | (((cbp >> 1) & 1) << 2) | (((cbp >> 2) & 1) << 1) | ((cbp >> 3) & 1)
+        bw.code(CBPY[luma if intra else (~luma & 15)])
+        if dq:
+            bw.code(DQUANT_CODE[dq])
+            quant += dq
+        cur = [[0, 0]] * 4
+        if not intra:
+            cur = [list(x) for x in cur]
+            for k in range(4 if four else 1):
+                p = predict(pv, cur, mbw, k)
+                bw.code(MVD[mvd_for(int(mv[k][0]), p[0])])
+                bw.code(MVD[mvd_for(int(mv[k][1]), p[1])])
+                cur[k] = [int(mv[k][0]), int(mv[k][1])]
+            if not four:
+                cur = [cur[0]] * 4
+        pv.append(cur)
+        ci = int(m["coeff_index"])
+        for b in range(6):
+            coded = (cbp >> b) & 1
+            c = coeffs[ci] if coded else None
+            extra = [(63, 1)] if (i, b) in overflow_blocks else ()
+            write_block(bw, c, intra, m["intradc"][b], coded, extra)
+            ci += coded
+    return bw.tobytes()

@@ -156,8 +156,9 @@ def test_state_errors_leave_state_unchanged():
     assert e.value.code == h263mi.ERR_INVALID_ARGUMENT
     assert_planes_equal(st.get_last_picture().as_yuv(), before, "after failed decode")
     with pytest.raises(h263mi.H263Error) as e:
-        st.decode_next_picture(b"\x00\x00\x80")
-    assert e.value.code == h263mi.ERR_UNIMPLEMENTED_DECODING
+        st.decode_next_picture(b"\x00\x00\x80")              # a bare start code: the header read hits EOF
+    assert e.value.code == -16
+    assert_planes_equal(st.get_last_picture().as_yuv(), before, "after failed bitstream decode")
     st.close()
 
 

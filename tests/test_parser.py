@@ -1,0 +1,115 @@
+"""Host bitstream parser (h263-rs_amd/host/bitstream.cpp) against every known answer the
+reference's in-source parser tests hold: bit reader (reader.rs:448-559), all code words of the MCBPC / CBPY /
+MVD / TCOEF tables (macroblock.rs:559-1010, block.rs:766-1705) and the eight hand-built block bitstreams
+incl. the Sorenson 7- and 11-bit escapes (block.rs:1707-2124).  Data: tests/golden/parser_reference_tests.json
+(tools/extract_golden.py); the reader cases are transcribed below (inputs and expected values only)."""
+import json
+import os
+
+import pytest
+
+import parselib as pl
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "parser_reference_tests.json")))
+MBTYPE = {"Inter": 0, "InterQ": 1, "Inter4V": 2, "Intra": 3, "IntraQ": 4, "Inter4Vq": 5}
+READ, PEEK, SKIP, READ_SIGNED, START_CODE = range(5)
+
+
+# ---- reader.rs:448-559 ---------------------------------------------------------------------------------
+def test_reader_unaligned_and_signed_reads():
+    assert pl.reader_script([0xFF, 0x72, 0x1C, 0x1F], [(READ, 3), (READ, 6), (READ, 23), (READ, 1)]) == \
+        [(0, 0x07), (0, 0x3E), (0, 0x721C1F), (pl.EOF_ERR, 0)]
+    r = pl.reader_script([0xFF, 0x40, 0x72, 0x1C, 0x1F], [(READ_SIGNED, 3), (READ_SIGNED, 6), (READ_SIGNED, 8),
+                                                          (READ_SIGNED, 23), (READ, 1)])
+    assert r == [(0, -1), (0, -2), (0, -0x80), (0, -0xDE3E1), (pl.EOF_ERR, 0)]
+    r = pl.reader_script([0xFF, 0x72, 0x1C, 0x1F], [(PEEK, 3), (PEEK, 6), (PEEK, 23)])
+    assert r == [(0, 0x07), (0, 0x3F), (0, 0x7FB90E)]
+
+
+def test_reader_bytes_and_words():
+    assert pl.reader_script([0xFE, 0x73, 0xF3], [(READ, 8)] * 3) == [(0, 0xFE), (0, 0x73), (0, 0xF3)]
+    assert pl.reader_script([0xFE, 0x73, 0xF3], [(SKIP, 2), (READ, 8), (READ, 8), (READ, 8)]) == \
+        [(0, 0), (0, 0xF9), (0, 0xCF), (pl.EOF_ERR, 0)]
+    assert pl.reader_script([0xFE, 0x73, 0x50, 0xF3], [(READ, 16), (READ, 16)]) == [(0, 0xFE73), (0, 0x50F3)]
+    assert pl.reader_script([0xFE, 0x73, 0x50, 0xF3], [(READ, 32)]) == [(0, 0xFE7350F3)]
+
+
+def test_reader_start_codes():
+    assert pl.reader_script([0x00, 0x00, 0x80, 0x00], [(START_CODE, 0)]) == [(0, 0)]
+    # stuffed: None (-1) at the aligned position, 3 bits ahead once one bit has been consumed
+    assert pl.reader_script([0x00, 0x00, 0x08, 0x00], [(START_CODE, 0), (SKIP, 1), (START_CODE, 0)]) == \
+        [(0, -1), (0, 0), (0, 3)]
+    assert pl.reader_script([0x13, 0x80, 0x00, 0x40, 0x00], [(START_CODE, 1)]) == [(0, 9)]
+
+
+# ---- code tables ---------------------------------------------------------------------------------------------
+def test_tcoef_table_every_code_word():
+    t = GOLD["tcoef_table"]
+    got = pl.read_vlc(pl.TCOEF, t["bytes"], len(t["expected"]))
+    assert len(got) == len(t["expected"]) == 102
+    for g, e in zip(got, t["expected"]):
+        assert g[0] == 1 and [bool(g[1]), int(g[2]), int(g[3])] == e, (g, e)
+    # ESCAPE: 0000 011
+    g = pl.read_vlc(pl.TCOEF, [0b00000110], 1)[0]
+    assert g[0] == 1 and g[1] == -1
+
+
+def _check_mcbpc(table, key):
+    t = GOLD[key]
+    got = pl.read_vlc(table, t["bytes"], len(t["expected"]))
+    assert len(got) == len(t["expected"])
+    for g, e in zip(got, t["expected"]):
+        if e == "stuffing":
+            assert g[0] == 1 and g[1] == -1, (g, e)
+        elif e == "invalid":
+            assert g[0] == 0, (g, e)
+        else:
+            assert g[0] == 1 and [int(g[1]), bool(g[2]), bool(g[3])] == [MBTYPE[e[0]], e[1], e[2]], (g, e)
+
+
+def test_mcbpc_tables_every_code_word():
+    _check_mcbpc(pl.MCBPC_I, "mcbpc_i")
+    _check_mcbpc(pl.MCBPC_P, "mcbpc_p")
+
+
+def test_cbpy_table_every_code_word():
+    t = GOLD["cbpy"]
+    got = pl.read_vlc(pl.CBPY, t["bytes"], len(t["expected"]))
+    assert len(got) == len(t["expected"])
+    for g, e in zip(got, t["expected"]):
+        if e is None:
+            assert g[0] == 0, (g, e)
+        else:
+            assert g[0] == 1 and [bool(g[1] & 8), bool(g[1] & 4), bool(g[1] & 2), bool(g[1] & 1)] == e, (g, e)
+
+
+def test_mvd_table_every_code_word():
+    t = GOLD["mvd"]
+    got = pl.read_vlc(pl.MVD, t["bytes"], len(t["expected"]))
+    assert len(got) == len(t["expected"])
+    for g, e in zip(got, t["expected"]):
+        if e is None:
+            assert g[0] == 0, (g, e)
+        else:
+            assert g[0] == 1 and g[1] == int(e * 2), (g, e)       # HalfPel::from(f32) = floor(v * 2)
+
+
+# ---- whole blocks (block.rs:1707-2124) ------------------------------------------------------------------------
+@pytest.mark.parametrize("case", GOLD["blocks"], ids=[b["name"] for b in GOLD["blocks"]])
+def test_decode_block_reference_cases(case):
+    rc, has_dc, code, tcoef, _ = pl.decode_block(case["bytes"], case["sorenson"], case["version"], case["intra"],
+                                                 case["tcoef_present"])
+    assert rc == 0
+    if case["intradc_level"] is None:
+        assert not has_dc
+    else:
+        assert has_dc and (1024 if code == 255 else code << 3) == case["intradc_level"]
+    assert [(bool(s), r, l) for s, r, l in tcoef] == [(bool(s), r, l) for s, r, l in case["tcoef"]]
+
+
+def test_decode_block_errors():
+    assert pl.decode_block([0x00], False, None, True, False)[0] == -5        # INTRADC 0 is illegal (types.rs:930-936)
+    assert pl.decode_block([0x80], False, None, True, False)[0] == -5        # INTRADC 128 too
+    assert pl.decode_block([0x00, 0x00], False, None, False, True)[0] == -6  # 0000 0000 0...: no TCOEF starts so
+    assert pl.decode_block([0b00000110, 0, 0], False, None, False, True)[0] == -7   # escape with LEVEL 0
+    assert pl.decode_block([0b10], False, None, False, True)[0] == pl.EOF_ERR  # data ends inside the code word

@@ -155,3 +155,121 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------
+# parser known answers: h263/src/parser/{reader,macroblock,block}.rs tests
+# ---------------------------------------------------------------------------------------------
+def _fn_body(src, name):
+    k = src.index("fn %s()" % name)
+    b = src.index("{", k)
+    inner, _ = balanced(src, b, "{", "}")
+    return inner
+
+
+def _byte_array(body, var):
+    k = body.index("let %s" % var)
+    b = body.index("[", body.index("=", k))
+    inner, _ = balanced(body, b, "[", "]")
+    out = []
+    for tok in re.findall(r"0b[01_]+|0x[0-9A-Fa-f]+|\d+", inner):
+        out.append(int(tok.replace("_", ""), 0))
+    return out
+
+
+def extract_parser():
+    out = {"source": "h263/src/parser/{reader,macroblock,block}.rs in-source tests (ruffle-rs/h263-rs @ 2025-04-10)"}
+    blk = strip_comments(open(os.path.join(REF, "h263/src/parser/block.rs")).read())
+    mb = strip_comments(open(os.path.join(REF, "h263/src/parser/macroblock.rs")).read())
+
+    # --- TCOEF table: every code word of Table 16/H.263 (block.rs:768-1705)
+    body = _fn_body(blk, "tcoef_table")
+    seq = []
+    for m in re.finditer(r"assert_eq!\(\s*reader\.read_vlc\(&TCOEF_TABLE\)\.unwrap\(\),\s*(.*?)\s*\);", body, re.S):
+        e = re.sub(r"\s+", " ", m.group(1))
+        r = re.search(r"last: (true|false), run: (\d+), level: (\d+)", e)
+        if r:
+            seq.append([r.group(1) == "true", int(r.group(2)), int(r.group(3))])
+        elif "EscapeToLong" in e:
+            seq.append("escape")
+        elif e.strip() == "None":
+            seq.append(None)
+        else:
+            raise ValueError(e)
+    out["tcoef_table"] = {"bytes": _byte_array(body, "bit_pattern"), "expected": seq}
+
+    # --- whole-block decodes (block.rs:1707-2124)
+    blocks = []
+    for name in ("empty_inter_block", "empty_intra_block", "long_coded_inter_block", "long_coded_intra_block",
+                 "short_coded_inter_block", "short_coded_intra_block", "sorenson_long_coded_intra_block",
+                 "sorenson_xlong_coded_intra_block"):
+        body = _fn_body(blk, name)
+        case = {"name": name, "bytes": _byte_array(body, "bitstream")}
+        case["version"] = int(re.search(r"version:\s*(None|Some\((\d+)\))", body).group(2) or -1) \
+            if "Some(" in re.search(r"version:\s*(None|Some\(\d+\))", body).group(1) else None
+        case["sorenson"] = "SORENSON_SPARK_BITSTREAM" in body
+        case["intra"] = "MacroblockType::Intra" in body
+        m = re.search(r"decode_block\((.*?)\)\s*\.unwrap", body, re.S)
+        args = [a.strip() for a in re.sub(r"\s+", " ", m.group(1)).split(",")]
+        case["tcoef_present"] = args[-1] == "true"
+        m = re.search(r"intradc:\s*(None|IntraDc::from_level\((0x[0-9A-Fa-f]+|\d+)\)|IntraDc::from_u8\((0x[0-9A-Fa-f]+|\d+)\))", body)
+        if m.group(1) == "None":
+            case["intradc_level"] = None
+        elif m.group(2):
+            case["intradc_level"] = int(m.group(2), 0)
+        else:
+            c = int(m.group(3), 0)
+            case["intradc_level"] = 1024 if c == 255 else c << 3
+        case["tcoef"] = [[t[0] == "true", int(t[1]), int(t[2])] for t in
+                         re.findall(r"is_short:\s*(true|false),\s*run:\s*(\d+),\s*level:\s*(-?\d+)", body)]
+        blocks.append(case)
+    out["blocks"] = blocks
+
+    # --- macroblock layer tables (macroblock.rs:559-1010)
+    def table(fn, tbl, conv):
+        body = _fn_body(mb, fn)
+        seq = []
+        for m in re.finditer(r"assert_eq!\(\s*reader\.read_vlc\(&%s(?:\[\.\.\])?\)\.unwrap\(\),\s*(.*?)\s*\);" % tbl, body, re.S):
+            seq.append(conv(re.sub(r"\s+", " ", m.group(1)).strip()))
+        return {"bytes": _byte_array(body, "bit_pattern"), "expected": seq}
+
+    def conv_mcbpc(e):
+        if "Stuffing" in e:
+            return "stuffing"
+        if "Invalid" in e:
+            return "invalid"
+        r = re.search(r"MacroblockType::(\w+), (true|false), (true|false)", e)
+        return [r.group(1), r.group(2) == "true", r.group(3) == "true"]
+
+    def conv_cbpy(e):
+        if e == "None":
+            return None
+        return [v == "true" for v in re.findall(r"true|false", e)]
+
+    def conv_mvd(e):
+        if e == "None":
+            return None
+        return float(re.search(r"Some\((-?[\d.]+)\)", e).group(1))
+
+    out["mcbpc_i"] = table("macroblock_mcbpc_iframe", "MCBPC_I_TABLE", conv_mcbpc)
+    out["mcbpc_p"] = table("macroblock_mcbpc_pframe", "MCBPC_P_TABLE", conv_mcbpc)
+    out["cbpy"] = table("macroblock_cbpy_table", "CBPY_TABLE_INTRA", conv_cbpy)
+    out["mvd"] = table("macroblock_mvd_table", "MVD_TABLE", conv_mvd)
+    return out
+
+
+def main_parser():
+    p = extract_parser()
+    assert len(p["tcoef_table"]["expected"]) >= 100, len(p["tcoef_table"]["expected"])
+    assert len(p["blocks"]) == 8
+    assert len(p["mcbpc_i"]["expected"]) == 10 and len(p["mcbpc_p"]["expected"]) >= 22
+    assert len(p["cbpy"]["expected"]) >= 16 and len(p["mvd"]["expected"]) >= 64
+    with open(os.path.join(OUT, "parser_reference_tests.json"), "w") as f:
+        json.dump(p, f, indent=1)
+    print("parser: tcoef %d, blocks %d, mcbpc_i %d, mcbpc_p %d, cbpy %d, mvd %d" % (
+        len(p["tcoef_table"]["expected"]), len(p["blocks"]), len(p["mcbpc_i"]["expected"]),
+        len(p["mcbpc_p"]["expected"]), len(p["cbpy"]["expected"]), len(p["mvd"]["expected"])))
+
+
+if __name__ == "__main__":
+    main_parser()

@@ -185,9 +185,18 @@ def main():
     for k in kernels.values():
         k["achieved_gbs"] = k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
     dom = "k_post" if kt.post_ms >= kt.recon_ms else "k_recon"
+    # HBM traffic of that kernel from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
+    # collected by tools/prof_final.sh in separate rocprofv3 --pmc runs of this same workload; null if absent)
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if n == 64 and world == 1:
+            traffic = tr["kernels"][dom]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(kernels[dom]["achieved_gbs"], 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kernels[dom]["achieved_gbs"] / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": round(kernels[dom]["avg_ms"], 4),
                 "alg_bytes_per_launch": int(kernels[dom]["alg_bytes_per_launch"]),
                 "pipeline_achieved": round((recon_alg + post_alg) * args.steps / elapsed / 1e9, 1),

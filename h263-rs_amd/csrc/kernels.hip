@@ -84,20 +84,54 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
 // neighbouring tiles at any moment: the cache lines that the 4-pixel tile offset makes two tiles
 // share are then fetched once per L2 instead of once per XCD.
 // ---------------------------------------------------------------------------------------
+// Two strips of a tile.  FETCH_AHEAD: queue the loads of the strips two further down right after each
+// commit, so that they are in flight while this pair is filtered and stored.
+template <bool FETCH_AHEAD>
+__device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s, PostFetch &pf0, PostFetch &pf1, int lane,
+                                                int sx, int sy, int pic)
+{
+    // `ln`: the lane index behind an opaque asm, re-derived per strip so that lane-only expressions (LDS
+    // offsets, column indices, ...) are recomputed where used instead of being kept in registers across
+    // the whole kernel -- the hoisted form cost half of the occupancy.
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    post_phase_commit(a, s, pf0, ln);
+    if (FETCH_AHEAD) post_phase_fetch(a, pf0, ln, sx, sy + 2, pic);
+    if (a.strength) {
+        post_phase_hedges(a, s, ln, sx, sy);
+        post_phase_vedges(a, s, ln, sx, sy);
+    }
+    post_phase_store(a, s, ln, sx, sy, pic);
+
+    asm volatile("" : "+v"(ln));
+    post_phase_commit(a, s, pf1, ln);
+    if (FETCH_AHEAD) post_phase_fetch(a, pf1, ln, sx, sy + 3, pic);
+    if (a.strength) {
+        post_phase_hedges(a, s, ln, sx, sy + 1);
+        post_phase_vedges(a, s, ln, sx, sy + 1);
+    }
+    post_phase_store(a, s, ln, sx, sy + 1, pic);
+}
+
 __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 {
     __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PostStrip &s = strips[wave];
-    // one wave = one 128x32 tile = 4 strips; a workgroup = 4 consecutive tiles of the XCD-ordered list
-    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures;
-    const uint32_t wgs = (total + POST_WAVES - 1) / POST_WAVES, chunk = (wgs + 7) / 8, xcd = blockIdx.x & 7;
+    // one wave = one 128x32 tile = 4 strips; a workgroup = 4 vertically adjacent tiles (a 128x128 block), and
+    // workgroups follow each other along x in the XCD-ordered list.  Horizontal neighbours -- which share the
+    // cache lines the 4-pixel tile offset straddles -- are thus in different workgroups, start at slightly
+    // different times, and the second one finds the shared lines in L2 (4 lock-stepped waves of one
+    // workgroup missing on the same line at the same moment fetched it twice: +50 % FETCH_SIZE).
+    const uint32_t groups_y = (a.tiles_y + POST_WAVES - 1) / POST_WAVES;
+    const uint32_t wpp = a.tiles_x * groups_y, wgs = wpp * a.n_pictures;
+    const uint32_t chunk = (wgs + 7) / 8, xcd = blockIdx.x & 7;
     const uint32_t t = blockIdx.x >> 3, wg = xcd * chunk + t;
     if (t >= chunk || wg >= wgs) return;
-    const uint32_t g = wg * POST_WAVES + wave;
-    if (g >= total) return;
-    const int pic = (int)(g / tpp), tile = (int)(g % tpp);
-    const int sx = tile % (int)a.tiles_x, sy0 = (tile / (int)a.tiles_x) * POST_STRIPS;
+    const int pic = (int)(wg / wpp), rem = (int)(wg % wpp);
+    const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_WAVES + wave;
+    if (ty >= (int)a.tiles_y) return;
+    const int sy0 = ty * POST_STRIPS;
     // no workgroup barrier anywhere: the wave owns its strips from load to store.  All loads of the
     // tile are queued first; each strip then waits only for its own.
     // Two strips are always in flight ahead of the one being filtered.  Strips past the bottom of the
@@ -106,37 +140,14 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     PostFetch pf0, pf1;
     post_phase_fetch(a, pf0, lane, sx, sy0, pic);
     post_phase_fetch(a, pf1, lane, sx, sy0 + 1, pic);
-#pragma unroll 1
-    for (int k = 0; k < POST_STRIPS; k += 2) {
-        // `ln` is re-derived in every iteration behind an opaque asm, so that lane-only expressions
-        // (LDS offsets, column indices, ...) are recomputed where used instead of being hoisted out of
-        // the loop and pinned in registers for its whole length: recomputing is a few cheap VALU ops,
-        // while the hoisted form cost half of the occupancy.
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        post_phase_commit(a, s, pf0, ln);
-        post_phase_fetch(a, pf0, ln, sx, sy0 + k + 2, pic);
-        if (a.strength) {
-            post_phase_hedges(a, s, ln, sx, sy0 + k);
-            post_phase_vedges(a, s, ln, sx, sy0 + k);
-        }
-        post_phase_store(a, s, ln, sx, sy0 + k, pic);
-
-        asm volatile("" : "+v"(ln));
-        post_phase_commit(a, s, pf1, ln);
-        post_phase_fetch(a, pf1, ln, sx, sy0 + k + 3, pic);
-        if (a.strength) {
-            post_phase_hedges(a, s, ln, sx, sy0 + k + 1);
-            post_phase_vedges(a, s, ln, sx, sy0 + k + 1);
-        }
-        post_phase_store(a, s, ln, sx, sy0 + k + 1, pic);
-    }
+    post_strip_pair<true>(a, s, pf0, pf1, lane, sx, sy0, pic);          // strips 0,1; queues the loads of 2,3
+    post_strip_pair<false>(a, s, pf0, pf1, lane, sx, sy0 + 2, pic);     // strips 2,3
 }
 
 hipError_t launch_post(const PostArgs &args, hipStream_t stream)
 {
-    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures;
-    const uint32_t wgs = (total + POST_WAVES - 1) / POST_WAVES, chunk = (wgs + 7) / 8;
+    const uint32_t groups_y = (args.tiles_y + POST_WAVES - 1) / POST_WAVES;
+    const uint32_t wgs = args.tiles_x * groups_y * args.n_pictures, chunk = (wgs + 7) / 8;
     hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, args);
     return hipGetLastError();
 }

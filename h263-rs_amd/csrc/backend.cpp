@@ -255,52 +255,60 @@ struct h263mi_state {
     h263mi_batch *b = nullptr;
     h263mi_picture_desc last_desc{};
     bool has_last = false;
-    // staging
-    MbRecord *h_mbs = nullptr;  int16_t *h_coeffs = nullptr;     // pinned
-    MbRecord *d_mbs = nullptr;  int16_t *d_coeffs = nullptr;
-    size_t cap_mbs = 0, cap_blocks = 0;
+    // staging: two slots (pinned host + device) used alternately, so that filling slot i+1 on the host
+    // overlaps the H2D copy and the kernel of slot i
+    struct Staging {
+        MbRecord *h_mbs = nullptr;  int16_t *h_coeffs = nullptr;     // pinned
+        MbRecord *d_mbs = nullptr;  int16_t *d_coeffs = nullptr;
+        size_t cap_mbs = 0, cap_blocks = 0;
+        hipEvent_t done = nullptr;  // recorded after the kernel that reads the slot
+    } stg[2];
+    unsigned next_slot = 0;
     uint8_t *d_rgba = nullptr;  size_t cap_rgba = 0;
-    hipEvent_t staged = nullptr;
 
     void free_staging()
     {
-        if (h_mbs) (void)hipHostFree(h_mbs);
-        if (h_coeffs) (void)hipHostFree(h_coeffs);
-        if (d_mbs) (void)hipFree(d_mbs);
-        if (d_coeffs) (void)hipFree(d_coeffs);
+        for (Staging &g : stg) {
+            if (g.h_mbs) (void)hipHostFree(g.h_mbs);
+            if (g.h_coeffs) (void)hipHostFree(g.h_coeffs);
+            if (g.d_mbs) (void)hipFree(g.d_mbs);
+            if (g.d_coeffs) (void)hipFree(g.d_coeffs);
+            if (g.done) (void)hipEventDestroy(g.done);
+            g = Staging();
+        }
         if (d_rgba) (void)hipFree(d_rgba);
-        h_mbs = nullptr; h_coeffs = nullptr; d_mbs = nullptr; d_coeffs = nullptr; d_rgba = nullptr;
-        cap_mbs = cap_blocks = cap_rgba = 0;
+        d_rgba = nullptr;
+        cap_rgba = 0;
     }
     ~h263mi_state()
     {
         DeviceGuard g(cfg.device_id);
         if (b) (void)hipStreamSynchronize(b->stream);
         free_staging();
-        if (staged) (void)hipEventDestroy(staged);
         delete b;
     }
 };
 
-static int state_ensure_staging(h263mi_state *s, size_t n_mbs, size_t n_blocks)
+static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n_blocks)
 {
-    if (n_mbs > s->cap_mbs) {
-        if (s->h_mbs) (void)hipHostFree(s->h_mbs);
-        if (s->d_mbs) (void)hipFree(s->d_mbs);
-        s->h_mbs = nullptr; s->d_mbs = nullptr; s->cap_mbs = 0;
-        HIP_TRY(hipHostMalloc((void **)&s->h_mbs, n_mbs * sizeof(MbRecord), hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&s->d_mbs, n_mbs * sizeof(MbRecord)));
-        s->cap_mbs = n_mbs;
+    if (n_mbs > g.cap_mbs) {
+        if (g.h_mbs) (void)hipHostFree(g.h_mbs);
+        if (g.d_mbs) (void)hipFree(g.d_mbs);
+        g.h_mbs = nullptr; g.d_mbs = nullptr; g.cap_mbs = 0;
+        HIP_TRY(hipHostMalloc((void **)&g.h_mbs, n_mbs * sizeof(MbRecord), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&g.d_mbs, n_mbs * sizeof(MbRecord)));
+        g.cap_mbs = n_mbs;
     }
-    if (n_blocks > s->cap_blocks) {
-        if (s->h_coeffs) (void)hipHostFree(s->h_coeffs);
-        if (s->d_coeffs) (void)hipFree(s->d_coeffs);
-        s->h_coeffs = nullptr; s->d_coeffs = nullptr; s->cap_blocks = 0;
+    if (n_blocks > g.cap_blocks) {
+        if (g.h_coeffs) (void)hipHostFree(g.h_coeffs);
+        if (g.d_coeffs) (void)hipFree(g.d_coeffs);
+        g.h_coeffs = nullptr; g.d_coeffs = nullptr; g.cap_blocks = 0;
         size_t cap = n_blocks + n_blocks / 2 + 64;
-        HIP_TRY(hipHostMalloc((void **)&s->h_coeffs, cap * 128, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&s->d_coeffs, cap * 128));
-        s->cap_blocks = cap;
+        HIP_TRY(hipHostMalloc((void **)&g.h_coeffs, cap * 128, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&g.d_coeffs, cap * 128));
+        g.cap_blocks = cap;
     }
+    if (!g.done) HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     return H263MI_OK;
 }
 
@@ -498,26 +506,27 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, cons
         s->has_last = false;
     }
     h263mi_batch *b = s->b;
-    RC_TRY(state_ensure_staging(s, total, n_coeff_blocks ? n_coeff_blocks : 1));
-    if (!s->staged) HIP_TRY(hipEventCreateWithFlags(&s->staged, hipEventDisableTiming));
-    HIP_TRY(hipEventSynchronize(s->staged));     // previous upload finished: staging is reusable
+    h263mi_state::Staging &g2 = s->stg[s->next_slot & 1];
+    RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1));
+    HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
 
-    memcpy(s->h_mbs, mbs, n_mbs * sizeof(MbRecord));
+    memcpy(g2.h_mbs, mbs, n_mbs * sizeof(MbRecord));
     for (size_t i = n_mbs; i < total; i++) {     // state.rs:421-427: Inter, mv (0,0), nothing coded
         MbRecord pad;
         memset(&pad, 0, sizeof pad);
         pad.mb_type = H263MI_MB_INTER;
         pad.quant = 1;
-        s->h_mbs[i] = pad;
+        g2.h_mbs[i] = pad;
     }
-    if (n_coeff_blocks) memcpy(s->h_coeffs, coeffs, n_coeff_blocks * 128);
-    HIP_TRY(hipMemcpyAsync(s->d_mbs, s->h_mbs, total * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
+    if (n_coeff_blocks) memcpy(g2.h_coeffs, coeffs, n_coeff_blocks * 128);
+    HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, total * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
     if (n_coeff_blocks)
-        HIP_TRY(hipMemcpyAsync(s->d_coeffs, s->h_coeffs, n_coeff_blocks * 128, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipEventRecord(s->staged, b->stream));
+        HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, n_coeff_blocks * 128, hipMemcpyHostToDevice, b->stream));
 
     b->coeff_pool_blocks = n_coeff_blocks;
-    RC_TRY(b->submit(desc->picture_type, s->d_mbs, s->d_coeffs, nullptr));
+    RC_TRY(b->submit(desc->picture_type, g2.d_mbs, g2.d_coeffs, nullptr));
+    HIP_TRY(hipEventRecord(g2.done, b->stream));
+    s->next_slot++;
     s->last_desc = *desc;
     s->has_last = true;
     return H263MI_OK;

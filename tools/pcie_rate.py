@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the single-stream path (never the headline `value`): host records through
+h263mi_submit_picture (pinned staging + async H2D + k_recon) and render_rgba with D2H of the frame, one 1080p
+stream."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "h263-rs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+
+import h263mi
+
+W, H = 1920, 1080
+st = h263mi.H263State()
+frames = []
+for f in range(8):
+    kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
+    frames.append((h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P,) + h263mi.synth_picture_host(kind, W, H, 0, f))
+
+
+def run(n, rgba):
+    t0 = time.perf_counter()
+    for i in range(n):
+        pt, mbs, co = frames[i % 8]
+        st.submit_picture(W, H, mbs, co, pt)
+        if rgba:
+            st.render_rgba(5)
+    if not rgba:
+        st.get_last_picture()
+    return (time.perf_counter() - t0) / n
+
+
+run(8, False)
+dt = run(64, False)
+rec_mb = np.mean([m.nbytes + c.nbytes for _, m, c in frames]) / 1e6
+print("submit_picture (host records, %.2f MB/picture mean): %.3f ms/picture = %.0f pictures/s = %.1f MP/s, H2D %.1f GB/s"
+      % (rec_mb, dt * 1e3, 1 / dt, W * H / 1e6 / dt, rec_mb / 1e3 / dt))
+dt = run(32, True)
+print("submit_picture + render_rgba(5) + D2H of 8.3 MB RGBA: %.3f ms/picture = %.0f pictures/s = %.1f MP/s"
+      % (dt * 1e3, 1 / dt, W * H / 1e6 / dt))
+dense = h263mi.synth_picture_host(h263mi.SYNTH_I_DENSE, W, H, 0, 0)
+t0 = time.perf_counter()
+for i in range(32):
+    st.submit_picture(W, H, dense[0], dense[1], h263mi.PICTURE_I)
+st.get_last_picture()
+dt = (time.perf_counter() - t0) / 32
+print("dense I pictures (%.2f MB of records each): %.3f ms/picture = %.0f pictures/s, H2D %.1f GB/s"
+      % ((dense[0].nbytes + dense[1].nbytes) / 1e6, dt * 1e3, 1 / dt, (dense[0].nbytes + dense[1].nbytes) / 1e9 / dt))

@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--gop", type=int, default=31)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="k_post on a second stream (post of picture i beside recon of picture i+1); measured: no gain, "
+                         "both kernels fill the chip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +160,7 @@ def main():
     n = args.streams
     my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU
     wl = Workload(n, args.gop, my_streams[0], local_rank, stream)
-    batch = h263mi.Batch(n, W, H, local_rank, stream)
+    batch = h263mi.Batch(n, W, H, local_rank, stream, overlap_post=args.overlap)
     d_rgba = h263mi.DeviceBuffer(n * RGBA_BYTES, local_rank)
 
     run_steps(batch, wl, d_rgba, 0, args.warmup)

@@ -69,6 +69,13 @@ uint32_t post_tiles_y(const FrameLayout &L) { return (post_strips_y(L.height) + 
 struct h263mi_batch {
     int device = 0;
     hipStream_t stream = nullptr;
+    // H263MI_CFG_OVERLAP_POST: k_post runs on a second stream so that the post-processing of picture i overlaps
+    // the reconstruction of picture i+1 (k_recon is VALU-heavy, k_post store-heavy).  Legal with two frame sets:
+    // post(i) reads set i; recon(i+1) reads set i and overwrites the set of picture i-1, which post(i-1) must have
+    // finished reading -- both dependencies are HIP events.
+    hipStream_t post_stream = nullptr;
+    hipEvent_t ev_recon_done = nullptr, ev_post_done = nullptr;
+    bool overlap_post = false;
     uint32_t n = 0;
     FrameLayout L{};
     uint8_t *frames[2] = {nullptr, nullptr};   // ping-pong frame sets, n * frame_bytes each
@@ -114,10 +121,18 @@ struct h263mi_batch {
         DeviceGuard g(device);
         (void)hipStreamSynchronize(stream);
         release_frames();
+        if (post_stream) {
+            (void)hipStreamSynchronize(post_stream);
+            (void)hipStreamDestroy(post_stream);
+        }
+        if (ev_recon_done) (void)hipEventDestroy(ev_recon_done);
+        if (ev_post_done) (void)hipEventDestroy(ev_post_done);
         if (d_status) (void)hipFree(d_status);
         if (h_status) (void)hipHostFree(h_status);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
+
+    hipStream_t stream_of(int kernel_id) const { return (kernel_id == 1 && overlap_post) ? post_stream : stream; }
 
     int time_begin(int kernel_id)
     {
@@ -130,13 +145,13 @@ struct h263mi_batch {
             }
         }
         ev_ranges.emplace_back(ev_used, kernel_id);
-        HIP_TRY(hipEventRecord(ev_pool[ev_used], stream));
+        HIP_TRY(hipEventRecord(ev_pool[ev_used], stream_of(kernel_id)));
         return H263MI_OK;
     }
-    int time_end()
+    int time_end(int kernel_id)
     {
         if (!timing) return H263MI_OK;
-        HIP_TRY(hipEventRecord(ev_pool[ev_used + 1], stream));
+        HIP_TRY(hipEventRecord(ev_pool[ev_used + 1], stream_of(kernel_id)));
         ev_used += 2;
         return H263MI_OK;
     }
@@ -160,9 +175,11 @@ struct h263mi_batch {
         a.has_ref = (has_ref && cur >= 0) ? 1u : 0u;
         a.tiles_x = recon_tiles_x(L);
         a.tiles_y = recon_tiles_y(L);
+        if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done, 0));   // the set being overwritten was read by post(i-1)
         RC_TRY(time_begin(0));
         HIP_TRY(launch_recon(a, stream));
-        RC_TRY(time_end());
+        RC_TRY(time_end(0));
+        if (overlap_post) HIP_TRY(hipEventRecord(ev_recon_done, stream));
         // reference bookkeeping, state.rs:464-483
         if (picture_type == H263MI_PICTURE_I) has_ref = false;
         cur = out;
@@ -184,14 +201,17 @@ struct h263mi_batch {
         a.tiles_x = post_tiles_x(L);
         a.tiles_y = post_tiles_y(L);
         a.luma_only = 0;
+        if (overlap_post) HIP_TRY(hipStreamWaitEvent(post_stream, ev_recon_done, 0));
         RC_TRY(time_begin(1));
-        HIP_TRY(launch_post(a, stream));
-        RC_TRY(time_end());
+        HIP_TRY(launch_post(a, stream_of(1)));
+        RC_TRY(time_end(1));
+        if (overlap_post) HIP_TRY(hipEventRecord(ev_post_done, post_stream));
         return H263MI_OK;
     }
 
     int sync()
     {
+        if (overlap_post) HIP_TRY(hipStreamSynchronize(post_stream));
         HIP_TRY(hipMemcpyAsync(h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         uint32_t st = *h_status;
@@ -237,7 +257,15 @@ static int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi
     if (!b) return H263MI_ERR_OUT_OF_MEMORY;
     b->device = dev;
     b->stream = cfg ? (hipStream_t)cfg->stream : nullptr;
-    int rc = b->alloc(n_streams, w, h);
+    int rc = H263MI_OK;
+    if (cfg && (cfg->flags & H263MI_CFG_OVERLAP_POST)) {
+        b->overlap_post = true;
+        if (hipStreamCreateWithFlags(&b->post_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_recon_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_post_done, hipEventDisableTiming) != hipSuccess)
+            rc = H263MI_ERR_HIP;
+    }
+    if (rc == H263MI_OK) rc = b->alloc(n_streams, w, h);
     if (rc != H263MI_OK) {
         delete b;
         return rc;
@@ -413,6 +441,7 @@ int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out)
     if (!b || !out) return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     b->timing = false;
+    if (b->overlap_post) HIP_TRY(hipStreamSynchronize(b->post_stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     *out = h263mi_kernel_times{};
     for (auto &r : b->ev_ranges) {

@@ -337,9 +337,9 @@ class DeviceBuffer:
 class Batch:
     """N independent streams advancing in lock step on one GPU (h263mi_batch_*)."""
 
-    def __init__(self, n_streams, width, height, device_id=0, stream=None):
+    def __init__(self, n_streams, width, height, device_id=0, stream=None, overlap_post=False):
         self.n, self.width, self.height, self.device_id = n_streams, width, height, device_id
-        self._cfg = BackendCfg(device_id, 0, stream)
+        self._cfg = BackendCfg(device_id, 1 if overlap_post else 0, stream)
         self._h = C.c_void_p()
         _check(lib().h263mi_batch_create(n_streams, width, height, C.byref(self._cfg), C.byref(self._h)),
                "batch_create")

@@ -121,7 +121,10 @@ typedef struct h263mi_picture_desc {
     uint16_t reserved1;
 } h263mi_picture_desc;                               /* 12 bytes */
 
-/* Where the back-end runs.  `stream` is a hipStream_t (NULL = the device's null stream). */
+/* Where the back-end runs.  `stream` is a hipStream_t (NULL = the device's null stream).
+ * flags: H263MI_CFG_OVERLAP_POST (batches only): h263mi_batch_render_rgba runs on a second, internal stream so
+ * that post-processing picture i overlaps reconstructing picture i+1; h263mi_batch_sync waits for both. */
+#define H263MI_CFG_OVERLAP_POST 0x1u
 typedef struct h263mi_backend_cfg {
     int32_t  device_id;
     uint32_t flags;

@@ -39,23 +39,29 @@ struct PostStrip {
 
 H263_HD uint32_t post_strips_y(uint32_t h) { return (h + 4 + POST_SH - 1) / POST_SH; }
 
-// One A,B,C,D quartet (deblock.rs:29-42 / 99-127).  floor_sem selects the SIMD-lane
-// semantics (>>) over the scalar ones (/).
+// One A,B,C,D quartet (deblock.rs:29-42 / 99-127).  The reference's SIMD lanes divide with arithmetic shifts
+// (floor), its scalar tails with `/` (truncation toward zero).  Both are one shift once a bias is added to
+// negative numerators: trunc(x / 2^k) = (x + ((x >> 31) & (2^k - 1))) >> k.  `tm` is 0 for the floor semantics
+// and all ones for truncation, so the bias vanishes where the reference shifts.
+H263_HD int div_pow2(int x, int k, int tm) { return (x + ((x >> 31) & ((1 << k) - 1) & tm)) >> k; }
+
 H263_HD void deblock_quartet(int &A, int &B, int &C, int &D, int strength, bool floor_sem)
 {
-    const int n = A - 4 * B + 4 * C - D;
-    const int d = floor_sem ? (n >> 3) : (n / 8);
-    const int ad = d < 0 ? -d : d;
+    const int tm = floor_sem ? 0 : -1;
+    const int ad_ = A - D;
+    const int d = div_pow2(ad_ + 4 * (C - B), 3, tm);
+    const int sd = d >> 31;                                   // 0 or -1
+    const int ad = (d ^ sd) - sd;                             // |d|
     // up_down_ramp (deblock.rs:13-15): signum(d) * max(0, |d| - max(0, 2*(|d| - strength)))
     int t = 2 * (ad - strength);
     t = t < 0 ? 0 : t;
     int mag = ad - t;
     mag = mag < 0 ? 0 : mag;
-    const int d1 = d < 0 ? -mag : mag;
-    const int half = floor_sem ? (d1 >> 1) : (d1 / 2);
-    const int lim = half < 0 ? -half : half;
-    const int q = floor_sem ? ((A - D) >> 2) : ((A - D) / 4);
-    const int d2 = clampi(q, -lim, lim);                      // clipd1 (deblock.rs:19-21)
+    const int d1 = (mag ^ sd) - sd;
+    const int half = div_pow2(d1, 1, tm);
+    const int sh = half >> 31;
+    const int lim = (half ^ sh) - sh;
+    const int d2 = clampi(div_pow2(ad_, 2, tm), -lim, lim);   // clipd1 (deblock.rs:19-21)
     A = (A - d2) & 0xff;                                      // `as u8`: wraps, no clamp
     B = clampi(B + d1, 0, 255);
     C = clampi(C - d1, 0, 255);
@@ -82,25 +88,25 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
     return;
 #endif
     {
+        // uniform base + 32-bit per-lane offset: the loads use scalar-base addressing, no 64-bit VALU adds
         const int row = lane >> 3, col = (lane & 7) * 16;
-        const uint32_t gy = (uint32_t)clampi(yl + row, 0, (int)a.L.rows_y - 1);
-        const uint8_t *src = frame + gy * a.L.pitch_y;
+        const uint32_t rowoff = (uint32_t)clampi(yl + row, 0, (int)a.L.rows_y - 1) * a.L.pitch_y;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int gx = clampi(xl + col + 4 * q, 0, (int)a.L.pitch_y - 4);
-            r.y[q] = *reinterpret_cast<const uint32_t *>(src + gx);
+            const uint32_t gx = (uint32_t)clampi(xl + col + 4 * q, 0, (int)a.L.pitch_y - 4);
+            r.y[q] = *reinterpret_cast<const uint32_t *>(frame + (rowoff + gx));
         }
     }
     {
         // (a luma-only call has no chroma planes: the loads still run, from the luma plane, and are ignored)
         const int plane = lane >> 5, row = (lane >> 3) & 3, col = (lane & 7) * 8;
         const int cxl = xl / 2, cyl = yl / 2;                 // xl, yl are even (and may be negative)
-        const uint32_t gy = (uint32_t)clampi(cyl + row, 0, (int)a.L.rows_c - 1);
-        const uint8_t *src = frame + (a.luma_only ? 0u : (plane ? a.L.off_cr : a.L.off_cb)) + gy * a.L.pitch_c;
+        const uint32_t rowoff = (a.luma_only ? 0u : (plane ? a.L.off_cr : a.L.off_cb)) +
+                                (uint32_t)clampi(cyl + row, 0, (int)a.L.rows_c - 1) * a.L.pitch_c;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int gx = clampi(cxl + col + 2 * q, 0, (int)a.L.pitch_c - 2);
-            r.c[q] = *reinterpret_cast<const uint16_t *>(src + gx);
+            const uint32_t gx = (uint32_t)clampi(cxl + col + 2 * q, 0, (int)a.L.pitch_c - 2);
+            r.c[q] = *reinterpret_cast<const uint16_t *>(frame + (rowoff + gx));
         }
     }
 }

@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libh263mi.so")
+LIB_PATH = os.environ.get("H263MI_LIB", os.path.join(_HERE, "libh263mi.so"))   # override: A/B runs of two builds
 
 OK = 0
 ERR_UNCODED_IFRAME_BLOCKS = -15

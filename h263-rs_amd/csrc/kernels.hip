@@ -26,18 +26,21 @@ __device__ __forceinline__ void lds_barrier()
 __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 {
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
     ReconWave &s = waves[wave];
-    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures;
+    // work list = (picture, tile, wave of the tile); a workgroup takes RECON_WAVES consecutive entries
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures * (TILE_WAVES / RECON_WAVES);
     const uint32_t chunk = (total + 7) / 8, xcd = blockIdx.x & 7;
     const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
     if (t >= chunk || g >= total) return;
-    const int tile = (int)(g % tpp);
+    const uint32_t tile_g = g / (TILE_WAVES / RECON_WAVES);
+    const int tw = (int)(g % (TILE_WAVES / RECON_WAVES)) * RECON_WAVES + wave;       // wave of the tile, 0..3
+    const int tile = (int)(tile_g % tpp);
     WavePos p;
-    p.pic = (int)(g / tpp);
+    p.pic = (int)(tile_g / tpp);
     p.mbx0 = (tile % (int)a.tiles_x) * TILE_MBX;
-    p.mby = (tile / (int)a.tiles_x) * TILE_MBY + (wave >> 1);
-    p.half = wave & 1;
+    p.mby = (tile / (int)a.tiles_x) * TILE_MBY + (tw >> 1);
+    p.half = tw & 1;
     if (p.mby >= (int)a.L.mbh) return;
     p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
 
@@ -69,7 +72,7 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
     }();
     ReconArgs a = args;
     a.debug_flags |= env_debug;
-    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures;
+    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures * (TILE_WAVES / RECON_WAVES);
     const uint32_t chunk = (total + 7) / 8;
     hipLaunchKernelGGL(k_recon, dim3(chunk * 8), dim3(RECON_THREADS), 0, stream, a);
     return hipGetLastError();
@@ -116,7 +119,7 @@ __device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s,
 __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 {
     __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
     PostStrip &s = strips[wave];
     // one wave = one 128x32 tile = 4 strips; a workgroup = 4 vertically adjacent tiles (a 128x128 block), and
     // workgroups follow each other along x in the XCD-ordered list.  Horizontal neighbours -- which share the

@@ -35,8 +35,12 @@
 
 namespace h263mi {
 
-constexpr int RECON_THREADS = 256;
-constexpr int RECON_WAVES = RECON_THREADS / 64;
+#ifndef H263MI_RECON_WAVES
+#define H263MI_RECON_WAVES 1       // measured: 1 -> 0.237 ms, 2 -> 0.241 ms, 4 -> 0.248 ms per launch (64 x 1080p P pictures)
+#endif
+constexpr int RECON_WAVES = H263MI_RECON_WAVES;      // waves per workgroup (they are independent: 1, 2 or 4)
+constexpr int RECON_THREADS = RECON_WAVES * 64;
+constexpr int TILE_WAVES = 4;                        // waves per 8x2-macroblock tile
 constexpr int TILE_MBX = 8, TILE_MBY = 2;      // macroblocks per workgroup
 constexpr int WAVE_TASKS = 24;                 // 16 luma + 8 chroma blocks per wave
 constexpr int ROUND_BLOCKS = 8;                // blocks per IDCT round (8 lanes each)
@@ -49,6 +53,8 @@ struct ReconWave {
     int16_t  mvc[TILE_MBX][2];                 // chroma vector per macroblock (gather.rs:182)
     uint32_t valid_mask;                       // bit m: macroblock m lies inside the picture
     uint32_t act_mask;                         // bit t: block task t goes through the IDCT
+    uint32_t inter_mask;                       // bit m: macroblock m is inside the picture and inter coded
+    uint32_t round_rows;                       // bit r: some block of the current IDCT round has a non-zero coefficient row r
     uint8_t  list[WAVE_TASKS];                 // compacted active tasks
     float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results; column 8 of each row keeps C[r][0] for the Vert class
     uint8_t  flags[ROUND_BLOCKS * 8];
@@ -75,33 +81,66 @@ H263_HD int task_mb(int t) { return t < 16 ? (t >> 1) : (t - 16); }
 H263_HD int task_blk(int t, int half) { return t < 16 ? (half * 2 + (t & 1)) : (4 + half); }
 
 // ---- packed helpers (device: single instructions; host build: plain C for tests/sim) ----------
-// per-byte (a + b + 1) >> 1
-H263_DEV uint32_t avg2_u8x4(uint32_t a, uint32_t b)
+// v_lerp_u8: per byte (a + b + (c & 1)) >> 1
+H263_DEV uint32_t lerp_u8x4(uint32_t a, uint32_t b, uint32_t c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_lerp(a, b, 0x01010101u);           // v_lerp_u8
+    return __builtin_amdgcn_lerp(a, b, c);
 #else
-    return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+    uint32_t out = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t x = (a >> (8 * k)) & 0xff, y = (b >> (8 * k)) & 0xff, r = (c >> (8 * k)) & 1;
+        out |= ((x + y + r) >> 1) << (8 * k);
+    }
+    return out;
 #endif
 }
 
-// per-byte (a + b + c + d + 2) >> 2
+// per-byte (a + b + 1) >> 1
+H263_DEV uint32_t avg2_u8x4(uint32_t a, uint32_t b) { return lerp_u8x4(a, b, 0x01010101u); }
+
+// per-byte (a + b + c + d + 2) >> 2, without leaving the packed bytes.  With a + b = 2*h1 + l1 and
+// c + d = 2*h2 + l2 the sum is 2*(h1 + h2) + (l1 + l2 + 2), so the result is
+// (h1 + h2 + 1 + (l1 & l2)) >> 1: the rounding average of the two floor averages, plus one exactly
+// where both low bits are set and h1 + h2 is even (an odd h1 + h2 absorbs the extra one).
+// avg4(a, a, b, b) == avg2(a, b) and avg4(a, a, a, a) == a, which is what lets the output phase use this
+// one form for all four half-pel cases.
 H263_DEV uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
+    const uint32_t h1 = lerp_u8x4(a, b, 0u), h2 = lerp_u8x4(c, d, 0u);
+    const uint32_t carry = (a ^ b) & (c ^ d) & ~(h1 ^ h2) & 0x01010101u;
+    return lerp_u8x4(h1, h2, 0x01010101u) + carry;
+}
+
+// clamp(v, lo, hi) for lo <= hi as one v_med3_i32
+H263_DEV int med3i(int v, int lo, int hi)
+{
 #if defined(__HIP_DEVICE_COMPILE__)
-    // even / odd bytes spread into 16-bit lanes by v_perm_b32, summed with v_add3_u32
-    const uint32_t EV = 0x0c020c00u, OD = 0x0c030c01u;
-    uint32_t e = __builtin_amdgcn_perm(0u, a, EV) + __builtin_amdgcn_perm(0u, b, EV) + __builtin_amdgcn_perm(0u, c, EV);
-    e = e + __builtin_amdgcn_perm(0u, d, EV) + 0x00020002u;
-    uint32_t o = __builtin_amdgcn_perm(0u, a, OD) + __builtin_amdgcn_perm(0u, b, OD) + __builtin_amdgcn_perm(0u, c, OD);
-    o = o + __builtin_amdgcn_perm(0u, d, OD) + 0x00020002u;
-    // bytes: e>>2 lane0, o>>2 lane0, e>>2 lane1, o>>2 lane1 (the permute drops the bits above each byte)
-    return __builtin_amdgcn_perm(o >> 2, e >> 2, 0x06020400u);
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
 #else
-    const uint32_t M = 0x00ff00ffu;
-    uint32_t e = (a & M) + (b & M) + (c & M) + (d & M) + 0x00020002u;
-    uint32_t o = ((a >> 8) & M) + ((b >> 8) & M) + ((c >> 8) & M) + ((d >> 8) & M) + 0x00020002u;
-    return ((e >> 2) & M) | (((o >> 2) & M) << 8);
+    return clampi(v, lo, hi);
+#endif
+}
+
+// row * pitch + x with 24-bit operands (one v_mad_u32_u24; rows and pitches are far below 2^24)
+H263_DEV uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b) + c;
+#else
+    return a * b + c;
+#endif
+}
+
+// a value every lane of the wave agrees on, moved to a scalar register
+H263_DEV uint32_t wave_uniform(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
 #endif
 }
 
@@ -159,18 +198,35 @@ typedef float f32x2 __attribute__((vector_size(8)));
 H263_CONST_TABLE float kBasis[8][8] = {H263MI_BASIS_ROWS};    // idct.rs:39-48
 
 H263_DEV f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
-H263_DEV f32x2 basis_pair(int f, int ip) { f32x2 r = {kBasis[f][2 * ip], kBasis[f][2 * ip + 1]}; return r; }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) float (*BasisPtr)[8];     // constant address space: scalar loads
+#else
+typedef const float (*BasisPtr)[8];
+#endif
+// The table pointer behind an opaque scalar asm: the 64 scalar registers the table occupies are then
+// (re)loaded where a pass starts instead of being held -- and spilled around -- for the whole kernel.
+H263_DEV BasisPtr basis_table()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    BasisPtr b = (BasisPtr)kBasis;
+    asm volatile("" : "+s"(b));
+    return b;
+#else
+    return kBasis;
+#endif
+}
+H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], B[f][2 * ip + 1]}; return r; }
 
 // idct_1d (idct.rs:52-65): out[i] = sum over f, in order, of in[f] * B[f][i].  The leading
 // "0.0 +" is dropped: it can only change the sign of a zero, which never reaches the integer result.
-H263_DEV void idct_1d_pairs(const float in[8], f32x2 out[4])
+H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4])
 {
 #pragma unroll
     for (int ip = 0; ip < 4; ip++) {
-        f32x2 acc = splat2(in[0]) * basis_pair(0, ip);
+        f32x2 acc = splat2(in[0]) * basis_pair(B, 0, ip);
 #pragma unroll
         for (int f = 1; f < 8; f++) {
-            f32x2 pr = splat2(in[f]) * basis_pair(f, ip);
+            f32x2 pr = splat2(in[f]) * basis_pair(B, f, ip);
             acc = acc + pr;
         }
         out[ip] = acc;
@@ -216,11 +272,12 @@ H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const
             if (p.mbx0 + m < (int)a.L.mbw && p.mby < (int)a.L.mbh) vm |= 1u << m;
         s.valid_mask = vm;
         s.act_mask = 0;
+        s.inter_mask = 0;
     }
 }
 
 // ---- phase 1: which blocks need the IDCT; chroma vectors -------------------------------
-H263_DEV void recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, const WavePos &p)
+H263_DEV void recon_phase_mark(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p)
 {
     if (lane < WAVE_TASKS) {
         const int m = task_mb(lane), blk = task_blk(lane, p.half);
@@ -243,6 +300,20 @@ H263_DEV void recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, const 
         const MbRecord &r = s.rec[m];
         s.mvc[m][0] = (int16_t)average_sum_of_mvs(r.mv[0][0] + r.mv[1][0] + r.mv[2][0] + r.mv[3][0]);
         s.mvc[m][1] = (int16_t)average_sum_of_mvs(r.mv[0][1] + r.mv[1][1] + r.mv[2][1] + r.mv[3][1]);
+        // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
+        const bool inter = ((s.valid_mask >> m) & 1) && mb_is_inter(r.mb_type);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t im = (uint32_t)(__ballot(inter) >> WAVE_TASKS);      // lanes 24..31 are the only ones here
+        if (m == 0) {
+            s.inter_mask = im;
+            if (im && !a.has_ref) atomicOr(a.status, STATUS_INTER_WITHOUT_REFERENCE);   // Error::UncodedIFrameBlocks
+        }
+#else
+        if (inter) {
+            s.inter_mask |= 1u << m;
+            if (!a.has_ref) *a.status |= STATUS_INTER_WITHOUT_REFERENCE;
+        }
+#endif
     }
 }
 
@@ -262,20 +333,21 @@ H263_DEV int recon_n_active(const ReconWave &s) { return popc32(s.act_mask); }
 // tap row: 9 are needed at most; a dwordx3 keeps it to one load per row).
 enum : uint8_t { SEG_INTER = 1, SEG_BORDER = 2 };
 struct SegFetch {
-    uint32_t r0[3], r1[3];     // reference row v and row v+1, bytes u .. u+11
-    int16_t  mvx, mvy;
-    uint8_t  flags;            // SEG_INTER: motion compensated (else prediction = 0);
-                               // SEG_BORDER: some tap falls outside the picture, redone with clamping
+    uint32_t r0[3], r1[3];     // reference rows v and v + 1, bytes u .. u+11 (r1 only where mvy is odd)
 };
 struct WaveFetch {
     SegFetch seg[3];           // [0], [1]: luma rows (lane>>4) and 4 + (lane>>4); [2]: chroma row lane>>3
+    uint32_t mvw[2];           // [0] luma (shared by segments 0 and 1), [1] chroma: mvx | mvy << 16;
+                               // (0, 0) when the macroblock takes no prediction
+    uint32_t flags;            // two bits per vector: SEG_INTER: motion compensated (else prediction = 0);
+                               // SEG_BORDER: some tap falls outside the picture, redone with clamping
     uint4    coef0;            // coefficient row of the first IDCT round
 };
 
-// segment k of a lane -> geometry
+// segment k of a lane -> geometry.  Segments 0 and 1 are the same luma column, four rows apart.
 struct SegGeo {
     int m, blk, task, px, py, pitch, pw, ph, resoff;   // resoff: index into the residual strip
-    uint32_t plane_off;
+    uint32_t plane_off;                                // uniform per (wave, k)
     bool luma;
 };
 
@@ -336,8 +408,9 @@ H263_DEV void fetch_row_clamped(const uint8_t *row, int u, int pw, uint32_t out[
 // The loads are issued unconditionally and in a fixed order -- coefficient row first, then two
 // 12-byte reference rows per segment -- so that the wait in front of the row pass can leave the six
 // reference loads in flight (s_waitcnt vmcnt(6)): the IDCT of this wave overlaps its own motion
-// compensation reads.  Lanes with nothing to fetch read a dummy line (always cache resident);
-// lanes whose taps leave the picture are fixed up later, in the output phase.
+// compensation reads.  A lane whose macroblock takes no prediction behaves like a zero vector (its
+// bytes are dropped in the output phase); lanes whose taps leave the picture are fixed up there too.
+// Every address is a wave-uniform plane base plus a 32-bit lane offset.
 H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, int lane, const WavePos &p)
 {
     const uint8_t *ref = a.ref + (size_t)p.pic * a.L.frame_bytes;
@@ -351,43 +424,52 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
             if ((rec.cbp >> blk) & 1) {
                 const uint64_t cidx = p.cbase + rec.coeff_index +
                                       (uint64_t)popc32(rec.cbp & ((1u << blk) - 1u));
-                if (!(a.coeff_pool_blocks && cidx >= a.coeff_pool_blocks) && !(a.debug_flags & 4))
+                if (!(a.coeff_pool_blocks && cidx >= a.coeff_pool_blocks))
                     src = reinterpret_cast<const uint8_t *>(a.coeffs + cidx * 64 + (size_t)r * 8);
             }
         }
         f.coef0 = *reinterpret_cast<const uint4 *>(src);       // uncoded slots ignore it
     }
+    // gather.rs:149: without a reference picture nothing is motion compensated (the error is already
+    // in the status word)
+    const uint32_t mc_mask = a.has_ref ? wave_uniform(s.inter_mask) : 0u;
+    f.flags = 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         SegFetch &sf = f.seg[k];
         const SegGeo g = seg_geometry(a, lane, k, p);
-        const MbRecord &rec = s.rec[g.m];
-        const bool valid = (s.valid_mask >> g.m) & 1;
-        const bool inter = valid && mb_is_inter(rec.mb_type);    // intra: prediction stays 0 (gather.rs:136-138)
-        if (inter && !a.has_ref && (lane & 15) == 0) {
-            // gather.rs:149 Error::UncodedIFrameBlocks -- reported through the status word
-#if defined(__HIP_DEVICE_COMPILE__)
-            atomicOr(a.status, STATUS_INTER_WITHOUT_REFERENCE);
-#else
-            *a.status |= STATUS_INTER_WITHOUT_REFERENCE;
-#endif
-        }
-        const bool mc = inter && a.has_ref;
-        sf.mvx = g.luma ? rec.mv[g.blk][0] : s.mvc[g.m][0];
-        sf.mvy = g.luma ? rec.mv[g.blk][1] : s.mvc[g.m][1];
+        const bool mc = (mc_mask >> g.m) & 1;
+        uint32_t mvw;                                   // (mvx, mvy) as one LDS word
+        if (g.luma) memcpy(&mvw, &s.rec[g.m].mv[g.blk][0], 4);
+        else memcpy(&mvw, &s.mvc[g.m][0], 4);
+        mvw = mc ? mvw : 0u;
+        const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int16_t)(mvw >> 16);
         // HalfPel::into_lerp_parameters (types.rs:721-729): floor(mv / 2), odd -> interpolate
-        const int u = g.px + (sf.mvx >> 1), v = g.py + (sf.mvy >> 1);
-        const bool inside = u >= 0 && u + 8 + (sf.mvx & 1) <= g.pw;
-        sf.flags = (uint8_t)((mc ? SEG_INTER : 0) | ((mc && !inside) ? SEG_BORDER : 0));
+        const int ix = mvx & 1, iy = mvy & 1;
+        const int u = g.px + (mvx >> 1), v = g.py + (mvy >> 1);
+        const bool inside = u >= 0 && u <= g.pw - 8 - ix;
+        if (k != 1) {
+            f.mvw[k >> 1] = mvw;
+            f.flags |= (uint32_t)((mc ? SEG_INTER : 0) | ((mc && !inside) ? SEG_BORDER : 0)) << (k & 2);
+        }
         // inside lanes read exactly at u (the 12-byte load may run past the row end: next row or padding);
         // border lanes read some mapped address, their data is replaced in the output phase
-        const uint32_t uc = (uint32_t)(inside ? u : clampi(u, 0, g.pitch - 12));
-        const uint32_t o0 = g.plane_off + (uint32_t)clampi(v, 0, g.ph - 1) * (uint32_t)g.pitch + uc;
-        const uint32_t o1 = g.plane_off + (uint32_t)clampi(v + 1, 0, g.ph - 1) * (uint32_t)g.pitch + uc;
-        const bool real = mc && !(a.debug_flags & 1);
-        load12(ref + (real ? o0 : 0u), sf.r0);
-        load12(ref + ((real && (sf.mvy & 1)) ? o1 : 0u), sf.r1);
+        const uint32_t uc = (uint32_t)(inside ? u : med3i(u, 0, g.pitch - 12));
+        const uint32_t row0 = (uint32_t)med3i(v, 0, g.ph - 1), row1 = (uint32_t)med3i(v + 1, 0, g.ph - 1);
+        // rows nobody needs (no prediction; integer vertical vector) read offset 0: one cache line for the
+        // whole wave instead of one per lane -- the address path is as loaded as the arithmetic here
+        // The loads themselves are dword aligned (bytes (uc & ~3) .. +11 still cover the 9 taps); the output
+        // phase shifts the window by uc & 3.  Misaligned dwordx3 loads measured ~5 % slower overall.
+        const uint8_t *plane = ref + g.plane_off;
+        const uint32_t ua = uc & ~3u;
+        load12(plane + (mc ? mad24(row0, (uint32_t)g.pitch, ua) : 0u), sf.r0);
+        load12(plane + (iy ? mad24(row1, (uint32_t)g.pitch, ua) : 0u), sf.r1);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the per-lane state as three vector registers: without this the compiler carries the lane
+    // predicates behind `flags` across the IDCT as scalar masks and spills other scalars around them
+    asm volatile("" : "+v"(f.flags), "+v"(f.mvw[0]), "+v"(f.mvw[1]));
+#endif
 }
 
 // ---- phase 4a: row pass ---------------------------------------------------------------
@@ -422,7 +504,7 @@ H263_DEV void recon_phase_idct_rows(const ReconArgs &a, ReconWave &s, const Wave
             // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r);
             // round 0 was loaded ahead of time by recon_phase_fetch
             uint4 raw = f.coef0;
-            if (round > 0 && !(a.debug_flags & 4))
+            if (round > 0)
                 raw = *reinterpret_cast<const uint4 *>(a.coeffs + cidx * 64 + (size_t)r * 8);
             const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
             const float two_q = (float)(2 * quant), qmp = (float)(quant - ((quant & 1) ? 0 : 1));
@@ -446,7 +528,7 @@ H263_DEV void recon_phase_idct_rows(const ReconArgs &a, ReconWave &s, const Wave
 
     // idct_1d over the coefficient row (idct.rs:52-65)
     f32x2 T[4];
-    idct_1d_pairs(C, T);
+    idct_1d_pairs(basis_table(), C, T);
     float *dst = &s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW];
 #pragma unroll
     for (int i = 0; i < 8; i++) dst[i] = T[i >> 1][i & 1];
@@ -478,11 +560,12 @@ H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, i
     for (int r = 0; r < 8; r++) col[r] = src[r * TBUF_ROW];
 
     f32x2 O[4];
-    idct_1d_pairs(col, O);
+    const BasisPtr B = basis_table();
+    idct_1d_pairs(B, col, O);
     // class fix-ups as one multiply and one add (both exact where they must not change the value):
     //   Vert: x * B[0][0] (idct.rs:160)          others: x * 1.0
     //   Dc  : x * 0 + dc * 0.5 (idct.rs:119: exactly 0.5, not B00*B00; dc = 0 gives the Zero class)
-    const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? kBasis[0][0] : 1.0f));
+    const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? B[0][0] : 1.0f));
     const f32x2 shift = splat2(dc_class ? c00 * 0.5f : 0.0f);
     int16_t *base = &s.res[(t < 16 ? t * 8 : 128 + (t - 16) * 8) + i];
 #pragma unroll
@@ -504,54 +587,53 @@ H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, i
 H263_DEV void recon_phase_output(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p)
 {
     uint8_t *cur = a.cur + (size_t)p.pic * a.L.frame_bytes;
+    const uint32_t valid_mask = wave_uniform(s.valid_mask), act_mask = wave_uniform(s.act_mask);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const SegGeo g = seg_geometry(a, lane, k, p);
-        if (!((s.valid_mask >> g.m) & 1)) continue;
+        if (!((valid_mask >> g.m) & 1)) continue;
         SegFetch sf = f.seg[k];
-        if (sf.flags & SEG_BORDER) {
+        const uint32_t mvw = f.mvw[k >> 1], flags = f.flags >> (k & 2);
+        const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int16_t)(mvw >> 16);
+        const int ix = mvx & 1, iy = mvy & 1;
+        const int u = g.px + (mvx >> 1);
+        uint32_t sh = (uint32_t)u & 3u;          // the rows were loaded from the dword at or below u
+        if (flags & SEG_BORDER) {
             // some tap lies outside the picture: redo the rows with per-tap clamping (gather.rs:24-25)
             const uint8_t *plane = a.ref + (size_t)p.pic * a.L.frame_bytes + g.plane_off;
-            const int u = g.px + (sf.mvx >> 1), v = g.py + (sf.mvy >> 1);
+            const int v = g.py + (mvy >> 1);
             fetch_row_clamped(plane + (size_t)clampi(v, 0, g.ph - 1) * g.pitch, u, g.pw, sf.r0);
-            if (sf.mvy & 1) fetch_row_clamped(plane + (size_t)clampi(v + 1, 0, g.ph - 1) * g.pitch, u, g.pw, sf.r1);
+            if (iy) fetch_row_clamped(plane + (size_t)clampi(v + 1, 0, g.ph - 1) * g.pitch, u, g.pw, sf.r1);
+            sh = 0;
         }
 
-        uint32_t lo = 0, hi = 0;                  // intra macroblocks start from zeros
-        if (sf.flags & SEG_INTER) {
-            if (a.debug_flags & 1) {
-                lo = hi = 0x01010101u * (uint32_t)(sf.mvx & 0xff);
-            } else {
-                const int ix = sf.mvx & 1, iy = sf.mvy & 1;
-                const uint32_t a0 = sf.r0[0], a1 = sf.r0[1];
-                lo = a0; hi = a1;
-                if (ix | iy) {
-                    const uint32_t s0 = alignbyte(sf.r0[1], sf.r0[0], 1), s1 = alignbyte(sf.r0[2], sf.r0[1], 1);
-                    if (iy) {
-                        const uint32_t b0 = sf.r1[0], b1 = sf.r1[1];
-                        if (ix) {
-                            const uint32_t t0 = alignbyte(sf.r1[1], sf.r1[0], 1), t1 = alignbyte(sf.r1[2], sf.r1[1], 1);
-                            lo = avg4_u8x4(a0, s0, b0, t0);      // gather.rs:103-111
-                            hi = avg4_u8x4(a1, s1, b1, t1);
-                        } else {
-                            lo = avg2_u8x4(a0, b0);              // gather.rs:115-121
-                            hi = avg2_u8x4(a1, b1);
-                        }
-                    } else {
-                        lo = avg2_u8x4(a0, s0);
-                        hi = avg2_u8x4(a1, s1);
-                    }
-                }
+        // One form for the four half-pel cases of gather.rs:84-132: the right-hand taps are the bytes
+        // one further (shift by ix), the lower taps come from row v + iy, and the four-tap average of
+        // repeated taps is the two-tap average or the tap itself.
+        const uint32_t a0 = alignbyte(sf.r0[1], sf.r0[0], sh), a1 = alignbyte(sf.r0[2], sf.r0[1], sh);
+        uint32_t lo = a0, hi = a1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__ballot(ix | iy))             // whole wave on integer vectors: the bytes are the prediction
+#endif
+        {
+            const uint32_t a2 = alignbyte(0u, sf.r0[2], sh);
+            uint32_t b0 = a0, b1 = a1, b2 = a2;                                          // row v + iy
+            if (iy) {
+                b0 = alignbyte(sf.r1[1], sf.r1[0], sh); b1 = alignbyte(sf.r1[2], sf.r1[1], sh); b2 = alignbyte(0u, sf.r1[2], sh);
             }
+            const uint32_t s0 = alignbyte(a1, a0, (uint32_t)ix), s1 = alignbyte(a2, a1, (uint32_t)ix);
+            const uint32_t t0 = alignbyte(b1, b0, (uint32_t)ix), t1 = alignbyte(b2, b1, (uint32_t)ix);
+            lo = avg4_u8x4(a0, s0, b0, t0);
+            hi = avg4_u8x4(a1, s1, b1, t1);
         }
-        if ((s.act_mask >> g.task) & 1) {
+        if (!(flags & SEG_INTER)) lo = hi = 0;             // intra macroblocks start from zeros (gather.rs:136-138)
+        if ((act_mask >> g.task) & 1) {
             const uint4 rv = *reinterpret_cast<const uint4 *>(&s.res[g.resoff]);
             lo = add_clip_u8x4(lo, rv.x, rv.y);
             hi = add_clip_u8x4(hi, rv.z, rv.w);
         }
         const uint64_t out = (uint64_t)lo | ((uint64_t)hi << 32);
-        if ((a.debug_flags & 2) && out != 0x123456789abcdef0ull) continue;                   // diagnosis
-        *reinterpret_cast<uint64_t *>(cur + (g.plane_off + (uint32_t)g.py * (uint32_t)g.pitch + (uint32_t)g.px)) = out;
+        *reinterpret_cast<uint64_t *>(cur + g.plane_off + mad24((uint32_t)g.py, (uint32_t)g.pitch, (uint32_t)g.px)) = out;
     }
 }
 

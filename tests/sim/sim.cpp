@@ -36,14 +36,14 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
     a.tiles_x = (a.L.mbw + TILE_MBX - 1) / TILE_MBX;
     a.tiles_y = (a.L.mbh + TILE_MBY - 1) / TILE_MBY;
     ReconWave *s = (ReconWave *)aligned_alloc(16, (sizeof(ReconWave) + 15) / 16 * 16);
-    // same work decomposition as kernels.hip::k_recon: XCD-ordered tiles, 4 independent waves per tile
+    // same work units as kernels.hip::k_recon: XCD-ordered tiles, 4 independent waves per tile (the order of units does not matter)
     const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * n_pictures, chunk = (total + 7) / 8;
     static WaveFetch f[64];
     for (uint32_t wg = 0; wg < chunk * 8; wg++) {
         const uint32_t xcd = wg & 7, t = wg >> 3, g = xcd * chunk + t;
         if (t >= chunk || g >= total) continue;
         const int tile = g % tpp;
-        for (int wave = 0; wave < RECON_WAVES; wave++) {
+        for (int wave = 0; wave < TILE_WAVES; wave++) {
             WavePos p;
             p.pic = g / tpp;
             p.mbx0 = (tile % (int)a.tiles_x) * TILE_MBX;

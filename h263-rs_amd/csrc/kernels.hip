@@ -56,9 +56,17 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 #pragma unroll 1
     for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
         asm volatile("" : "+v"(ln));
-        recon_phase_idct_rows(a, s, f, ln, p, round);
+        RowIn ri;
+        recon_phase_idct_load(a, s, f, ln, p, round, ri);
+        // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
+        const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
+                            (__ballot(ri.w[3] != 0) ? 8u : 0u);
+        const uint64_t rb = __ballot(recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm)));      // bit slot*8 + row
+        uint32_t rows_mask = (uint32_t)rb | (uint32_t)(rb >> 32);
+        rows_mask |= rows_mask >> 16;
+        rows_mask |= rows_mask >> 8;
         asm volatile("" : "+v"(ln));
-        recon_phase_idct_cols(a, s, ln, round);
+        recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu));
     }
     asm volatile("" : "+v"(ln));
     recon_phase_output(a, s, f, ln, p);

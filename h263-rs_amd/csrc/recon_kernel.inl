@@ -54,7 +54,6 @@ struct ReconWave {
     uint32_t valid_mask;                       // bit m: macroblock m lies inside the picture
     uint32_t act_mask;                         // bit t: block task t goes through the IDCT
     uint32_t inter_mask;                       // bit m: macroblock m is inside the picture and inter coded
-    uint32_t round_rows;                       // bit r: some block of the current IDCT round has a non-zero coefficient row r
     uint8_t  list[WAVE_TASKS];                 // compacted active tasks
     float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results; column 8 of each row keeps C[r][0] for the Vert class
     uint8_t  flags[ROUND_BLOCKS * 8];
@@ -219,18 +218,37 @@ H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], 
 
 // idct_1d (idct.rs:52-65): out[i] = sum over f, in order, of in[f] * B[f][i].  The leading
 // "0.0 +" is dropped: it can only change the sign of a zero, which never reaches the integer result.
-H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4])
+// Only the terms f < n are accumulated: the caller guarantees in[f] == 0 for f >= n, and adding a
+// zero product changes nothing but (again) the sign of a zero.  n is uniform over the wave, so the
+// early exits are scalar branches.
+H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n)
 {
 #pragma unroll
-    for (int ip = 0; ip < 4; ip++) {
-        f32x2 acc = splat2(in[0]) * basis_pair(B, 0, ip);
+    for (int ip = 0; ip < 4; ip++) out[ip] = splat2(in[0]) * basis_pair(B, 0, ip);
 #pragma unroll
-        for (int f = 1; f < 8; f++) {
-            f32x2 pr = splat2(in[f]) * basis_pair(B, f, ip);
-            acc = acc + pr;
+    for (int f = 1; f < 8; f++) {
+        if (f >= n) break;
+#pragma unroll
+        for (int ip = 0; ip < 4; ip++) {
+            const f32x2 pr = splat2(in[f]) * basis_pair(B, f, ip);
+            out[ip] = out[ip] + pr;
         }
-        out[ip] = acc;
     }
+}
+
+// Sparsity of one IDCT round, shared by the 8 blocks of the wave (what rle.rs:138-171 does per block
+// with its Horiz / Vert / Dc classes, generalised): number of leading coefficient columns (in pairs)
+// and rows that can be non-zero.
+H263_HD int cols_from_mask(uint32_t word_mask)      // bit j: some lane has a non-zero LEVEL in columns 2j, 2j+1
+{
+    return (word_mask & 8) ? 8 : (word_mask & 4) ? 6 : (word_mask & 2) ? 4 : 2;
+}
+H263_HD int rows_from_mask(uint32_t row_mask)       // bit r: some block has a non-zero coefficient in row r
+{
+    int n = 1;
+    for (int r = 1; r < 8; r++)
+        if ((row_mask >> r) & 1) n = r + 1;
+    return n;
 }
 
 // median of three = clamp(v, lo, hi) for lo <= hi (one v_med3_f32; no NaNs can occur here)
@@ -472,24 +490,29 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
 #endif
 }
 
-// ---- phase 4a: row pass ---------------------------------------------------------------
-H263_DEV void recon_phase_idct_rows(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
-                                    int round)
+// ---- phase 4a: coefficient row of the lane, row pass -----------------------------------------
+struct RowIn {
+    uint32_t w[4];             // the 8 LEVELs of the lane's coefficient row (zeros when the block has no TCOEF)
+    int16_t  quant, dc_level;  // dc_level: INTRADC level
+    uint8_t  active, use_dc;   // use_dc: intra block, row 0: the DC comes from INTRADC (rle.rs:117-121)
+};
+
+H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
+                                    int round, RowIn &ri)
 {
+    ri.w[0] = ri.w[1] = ri.w[2] = ri.w[3] = 0;
+    ri.quant = 1; ri.dc_level = 0; ri.active = 0; ri.use_dc = 0;
     const int slot = lane >> 3, r = lane & 7;
     const int k = round * ROUND_BLOCKS + slot;
     if (k >= recon_n_active(s)) return;
     const int t = s.list[k];
     const int m = task_mb(t), blk = task_blk(t, p.half);
     const MbRecord &rec = s.rec[m];
-    const bool coded = (rec.cbp >> blk) & 1;
-    const bool intra = mb_is_intra(rec.mb_type);
-    const int quant = rec.quant;
-
-    float C[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) C[c] = 0.0f;
-    if (coded) {
+    ri.active = 1;
+    ri.quant = rec.quant;
+    ri.use_dc = mb_is_intra(rec.mb_type) && r == 0;
+    ri.dc_level = (int16_t)intradc_level(rec.intradc[blk]);
+    if ((rec.cbp >> blk) & 1) {
         const uint64_t cidx = p.cbase + rec.coeff_index +
                               (uint64_t)popc32(rec.cbp & ((1u << blk) - 1u));
         if (a.coeff_pool_blocks && cidx >= a.coeff_pool_blocks) {
@@ -506,37 +529,58 @@ H263_DEV void recon_phase_idct_rows(const ReconArgs &a, ReconWave &s, const Wave
             uint4 raw = f.coef0;
             if (round > 0)
                 raw = *reinterpret_cast<const uint4 *>(a.coeffs + cidx * 64 + (size_t)r * 8);
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-            const float two_q = (float)(2 * quant), qmp = (float)(quant - ((quant & 1) ? 0 : 1));
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int level = (int)(int16_t)(w[c >> 1] >> ((c & 1) * 16));
-                C[c] = dequant_f32((float)level, two_q, qmp);
-            }
+            ri.w[0] = raw.x; ri.w[1] = raw.y; ri.w[2] = raw.z; ri.w[3] = raw.w;
         }
     }
-    // intra: the DC comes from INTRADC and TCOEFs start at zigzag 1 (rle.rs:117-121)
-    if (intra && r == 0) C[0] = (float)intradc_level(rec.intradc[blk]);
+}
+
+// lane's contribution to cols_from_mask
+H263_DEV uint32_t rowin_word_mask(const RowIn &ri)
+{
+    return (ri.w[1] ? 2u : 0u) | (ri.w[2] ? 4u : 0u) | (ri.w[3] ? 8u : 0u);
+}
+
+// Returns whether the lane's coefficient row holds anything non-zero (the caller folds these into
+// rows_from_mask's argument: a ballot on the device).
+H263_DEV bool recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols)
+{
+    if (!ri.active) return false;
+    const int slot = lane >> 3, r = lane & 7;
+    const int quant = ri.quant;
+    const float two_q = (float)(2 * quant), qmp = (float)(quant - ((quant & 1) ? 0 : 1));
+
+    float C[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        C[2 * j] = C[2 * j + 1] = 0.0f;
+        if (2 * j < n_cols) {                               // uniform
+            C[2 * j] = dequant_f32((float)(int)(int16_t)(ri.w[j] & 0xffffu), two_q, qmp);
+            C[2 * j + 1] = dequant_f32((float)((int)ri.w[j] >> 16), two_q, qmp);
+        }
+    }
+    if (ri.use_dc) C[0] = (float)ri.dc_level;
 
     // classification inputs (rle.rs:138-149): a non-zero value with y > 0 breaks "horiz",
     // one with x > 0 breaks "vert"
-    bool cols_nz = false, row_nz = (C[0] != 0.0f);
+    bool cols_nz = false;
 #pragma unroll
     for (int c = 1; c < 8; c++) cols_nz = cols_nz || (C[c] != 0.0f);
-    row_nz = (row_nz || cols_nz) && (r > 0);
-    s.flags[slot * 8 + r] = (uint8_t)((row_nz ? 1 : 0) | (cols_nz ? 2 : 0));
+    const bool row_any = cols_nz || (C[0] != 0.0f);
+    s.flags[slot * 8 + r] = (uint8_t)(((row_any && r > 0) ? 1 : 0) | (cols_nz ? 2 : 0));
 
     // idct_1d over the coefficient row (idct.rs:52-65)
     f32x2 T[4];
-    idct_1d_pairs(basis_table(), C, T);
+    idct_1d_pairs(basis_table(), C, T, n_cols);
     float *dst = &s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW];
 #pragma unroll
     for (int i = 0; i < 8; i++) dst[i] = T[i >> 1][i & 1];
     dst[8] = C[0];
+
+    return row_any;
 }
 
 // ---- phase 4b: column pass, rounding, residual strip -------------------------------------
-H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, int round)
+H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, int round, int n_rows)
 {
     const int slot = lane >> 3, i = lane & 7;
     const int k = round * ROUND_BLOCKS + slot;
@@ -557,11 +601,11 @@ H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, i
     const float *src = &s.tbuf[slot * TBUF_STRIDE + (vert ? 8 : i)];
     float col[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) col[r] = src[r * TBUF_ROW];
+    for (int r = 0; r < 8; r++) col[r] = r < n_rows ? src[r * TBUF_ROW] : 0.0f;       // uniform: rows >= n_rows are zero
 
     f32x2 O[4];
     const BasisPtr B = basis_table();
-    idct_1d_pairs(B, col, O);
+    idct_1d_pairs(B, col, O, n_rows);
     // class fix-ups as one multiply and one add (both exact where they must not change the value):
     //   Vert: x * B[0][0] (idct.rs:160)          others: x * 1.0
     //   Dc  : x * 0 + dc * 0.5 (idct.rs:119: exactly 0.5, not B00*B00; dc = 0 gives the Zero class)

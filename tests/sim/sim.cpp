@@ -58,8 +58,14 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
             for (int l = 0; l < 64; l++) recon_phase_fetch(a, *s, f[l], l, p);
             const int n_active = recon_n_active(*s);
             for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
-                for (int l = 0; l < 64; l++) recon_phase_idct_rows(a, *s, f[l], l, p, round);
-                for (int l = 0; l < 64; l++) recon_phase_idct_cols(a, *s, l, round);
+                static RowIn ri[64];
+                uint32_t wm = 0, rm = 0;
+                for (int l = 0; l < 64; l++) {
+                    recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l]);
+                    wm |= rowin_word_mask(ri[l]);          // the device kernel does these two reductions with ballots
+                }
+                for (int l = 0; l < 64; l++) rm |= recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm)) ? 1u << (l & 7) : 0u;
+                for (int l = 0; l < 64; l++) recon_phase_idct_cols(a, *s, l, round, rows_from_mask(rm));
             }
             for (int l = 0; l < 64; l++) recon_phase_output(a, *s, f[l], l, p);
         }

@@ -283,6 +283,7 @@ struct h263mi_state {
     h263mi_batch *b = nullptr;
     h263mi_picture_desc last_desc{};
     bool has_last = false;
+    bits::ParserContext parser_ctx;   // header + format of the last picture decoded from a bitstream (state.rs:143-167)
     // staging: two slots (pinned host + device) used alternately, so that filling slot i+1 on the host
     // overlaps the H2D copy and the kernel of slot i
     struct Staging {
@@ -485,6 +486,7 @@ int h263mi_state_reset(h263mi_state *s)
 {
     if (!s) return H263MI_ERR_INVALID_ARGUMENT;
     s->has_last = false;
+    s->parser_ctx = bits::ParserContext();
     if (s->b) {
         s->b->cur = -1;
         s->b->has_ref = false;
@@ -567,10 +569,11 @@ int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len,
     if (consumed) *consumed = 0;
     // serial half on the host (state.rs:143-427) ...
     bits::ParsedPicture pic;
-    RC_TRY(bits::parse_picture(data, len, s->options, pic));
+    RC_TRY(bits::parse_picture(data, len, s->options, &s->parser_ctx, pic));
     // ... everything from the cut line on (state.rs:421-483) on the GPU.  Nothing has touched the state so
     // far, so every error above leaves it unchanged, like the reader transaction of state.rs:142.
     RC_TRY(h263mi_submit_picture(s, &pic.desc, pic.mbs.data(), pic.mbs.size(), pic.coeffs.data(), pic.coeffs.size() / 64));
+    s->parser_ctx = pic.next;
     if (consumed) *consumed = pic.bits_consumed / 8;     // reader.commit() drains whole bytes (reader.rs:391-394)
     return H263MI_OK;
 }
@@ -581,7 +584,7 @@ int h263mi_parse_picture_header(const h263mi_state *s, const uint8_t *data, size
     bits::BitReader r(data, len);
     bits::PictureHeader h;
     bool is_picture = false;
-    RC_TRY(bits::decode_picture_header(r, s->options, h, is_picture));
+    RC_TRY(bits::decode_picture_header(r, s->options, &s->parser_ctx, h, is_picture));
     if (!is_picture) return H263MI_ERR_MIDDLE_OF_BITSTREAM;
     memset(out, 0, sizeof *out);
     out->width = h.width;

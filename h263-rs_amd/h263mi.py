@@ -18,9 +18,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("H263MI_LIB", os.path.join(_HERE, "libh263mi.so"))   # override: A/B runs of two builds
 
 OK = 0
-ERR_UNCODED_IFRAME_BLOCKS = -15
-ERR_UNIMPLEMENTED_DECODING = -17
-ERR_PICTURE_FORMAT_INVALID = -14
+# h263/src/error.rs:6-58, in order (include/h263mi.h)
+(ERR_INTERNAL_DECODER_ERROR, ERR_MIDDLE_OF_BITSTREAM, ERR_INVALID_MACROBLOCK_HEADER, ERR_INVALID_MACROBLOCK_CODED_BITS,
+ ERR_INVALID_INTRA_DC, ERR_INVALID_SHORT_COEFFICIENT, ERR_INVALID_LONG_COEFFICIENT, ERR_INVALID_MVD, ERR_INVALID_PTYPE,
+ ERR_INVALID_PLUS_PTYPE, ERR_INVALID_GOB_HEADER, ERR_INVALID_BITSTREAM, ERR_PICTURE_FORMAT_MISSING,
+ ERR_PICTURE_FORMAT_INVALID, ERR_UNCODED_IFRAME_BLOCKS, ERR_UNHANDLED_IO_ERROR, ERR_UNIMPLEMENTED_DECODING) = range(-1, -18, -1)
 ERR_INVALID_ARGUMENT = -100
 ERR_NO_DEVICE = -101
 ERR_NO_PICTURE = -104
@@ -28,6 +30,8 @@ ERR_NO_PICTURE = -104
 SORENSON_SPARK_BITSTREAM = 1
 USE_SCALABILITY_MODE = 2
 PICTURE_I, PICTURE_P, PICTURE_DISPOSABLE_P = 0, 1, 2
+(PICTURE_RESERVED_SORENSON, PICTURE_PB, PICTURE_IMPROVED_PB, PICTURE_B, PICTURE_EI, PICTURE_EP,
+ PICTURE_RESERVED) = range(3, 10)
 SYNTH_I_DENSE, SYNTH_I_MIXED, SYNTH_P = 0, 1, 2
 
 MB_RECORD_DTYPE = np.dtype([

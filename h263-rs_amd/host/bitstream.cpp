@@ -82,6 +82,28 @@ int BitReader::recognize_start_code(bool in_error, int &skipped) const
     return H263MI_OK;
 }
 
+int BitReader::read_umv(int &out)
+{
+    // reader.rs:298-324 (Table D.3/H.263): "1" = 0; otherwise pairs of bits: x0 continues with mantissa bit x,
+    // 00 ends positive, 10 ends negative; magnitudes of 4096 and above are an error
+    uint32_t v;
+    int rc = read_bits(1, v);
+    if (rc != H263MI_OK) return rc;
+    if (v == 1) { out = 0; return H263MI_OK; }
+    int mantissa = 0, bulk = 1;
+    while (bulk < 4096) {
+        if ((rc = read_bits(2, v)) != H263MI_OK) return rc;
+        switch (v) {
+        case 0: out = mantissa + bulk; return H263MI_OK;
+        case 2: out = -(mantissa + bulk); return H263MI_OK;
+        case 1: mantissa <<= 1; break;
+        default: mantissa = (mantissa << 1) | 1; break;
+        }
+        bulk <<= 1;
+    }
+    return H263MI_ERR_INVALID_MVD;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // VLC tables
 // ---------------------------------------------------------------------------------------------------
@@ -215,9 +237,284 @@ int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoe
 }
 
 // ---------------------------------------------------------------------------------------------------
-// picture layer, Sorenson branch: parser/picture.rs:611-661, 271-327, 577-596
+// picture layer: parser/picture.rs
 // ---------------------------------------------------------------------------------------------------
-int decode_picture_header(BitReader &r, uint32_t decoder_options, PictureHeader &out, bool &is_picture)
+bool SourceFormat::dimensions(uint16_t &w, uint16_t &h) const
+{
+    switch (kind) {                                              // types.rs:168-180
+    case SUB_QCIF: w = 128; h = 96; return true;
+    case QCIF: w = 176; h = 144; return true;
+    case CIF: w = 352; h = 288; return true;
+    case FOUR_CIF: w = 704; h = 576; return true;
+    case SIXTEEN_CIF: w = 1408; h = 1152; return true;
+    case EXTENDED: w = width; h = height; return true;
+    default: return false;                                       // Reserved (and a missing format)
+    }
+}
+
+namespace {
+#define RD(n, var) do { if ((rc = r.read_bits((n), var)) != H263MI_OK) return rc; } while (0)
+
+SourceFormat extended_format(uint16_t w, uint16_t h)
+{
+    SourceFormat f;
+    f.kind = SourceFormat::EXTENDED; f.par = 1; f.width = w; f.height = h;      // PixelAspectRatio::Square
+    return f;
+}
+SourceFormat plain_format(uint8_t kind)
+{
+    SourceFormat f;
+    f.kind = kind;
+    return f;
+}
+
+// decode_pei (picture.rs:577-596)
+int decode_pei(BitReader &r, std::vector<uint8_t> &extra)
+{
+    int rc;
+    uint32_t v;
+    for (;;) {
+        RD(1, v);
+        if (!v) return H263MI_OK;
+        RD(8, v);
+        extra.push_back((uint8_t)v);
+    }
+}
+
+// Sorenson header after the version field (picture.rs:626-659, decode_sorenson_ptype 271-327)
+int decode_sorenson_header(BitReader &r, PictureHeader &out)
+{
+    int rc;
+    uint32_t v, fmt;
+    RD(8, v);
+    out.temporal_reference = (uint16_t)v;
+    RD(3, fmt);
+    switch (fmt) {
+    case 0:
+    case 1: {
+        const uint32_t n = fmt == 0 ? 8 : 16;
+        uint32_t w, h;
+        RD(n, w);
+        RD(n, h);
+        out.format = extended_format((uint16_t)w, (uint16_t)h);
+        break;
+    }
+    case 2: out.format = plain_format(SourceFormat::CIF); break;
+    case 3: out.format = plain_format(SourceFormat::QCIF); break;
+    case 4: out.format = plain_format(SourceFormat::SUB_QCIF); break;
+    case 5: out.format = extended_format(320, 240); break;
+    case 6: out.format = extended_format(160, 120); break;
+    default: out.format = plain_format(SourceFormat::RESERVED); break;
+    }
+    RD(2, v);
+    out.picture_type = (uint8_t)v;               // 0 I, 1 P, 2 disposable P, 3 Reserved(3)
+    RD(1, v);
+    out.use_deblocker = v == 1;
+    if (v) out.options |= OPT_USE_DEBLOCKER;
+    RD(5, v);
+    out.quantizer = (uint8_t)v;
+    if ((rc = decode_pei(r, out.extra)) != H263MI_OK) return rc;
+    out.mv_range = 2;                            // "Sorenson is always unlimited" (picture.rs:644)
+    return H263MI_OK;
+}
+
+// decode_ptype (picture.rs:21-79); *plus = true: PLUSPTYPE follows and nothing else was read
+int decode_ptype(BitReader &r, PictureHeader &out, bool &plus)
+{
+    int rc;
+    uint32_t hi, lo;
+    plus = false;
+    RD(8, hi);
+    if ((hi & 0xC0) != 0x80) return H263MI_ERR_INVALID_PTYPE;
+    if (hi & 0x20) out.options |= OPT_USE_SPLIT_SCREEN;
+    if (hi & 0x10) out.options |= OPT_USE_DOCUMENT_CAMERA;
+    if (hi & 0x08) out.options |= OPT_RELEASE_FULL_PICTURE_FREEZE;
+    switch (hi & 7) {
+    case 0: return H263MI_ERR_INVALID_PTYPE;
+    case 1: out.format = plain_format(SourceFormat::SUB_QCIF); break;
+    case 2: out.format = plain_format(SourceFormat::QCIF); break;
+    case 3: out.format = plain_format(SourceFormat::CIF); break;
+    case 4: out.format = plain_format(SourceFormat::FOUR_CIF); break;
+    case 5: out.format = plain_format(SourceFormat::SIXTEEN_CIF); break;
+    case 6: out.format = plain_format(SourceFormat::RESERVED); break;
+    default: plus = true; return H263MI_OK;
+    }
+    RD(5, lo);
+    out.picture_type = (lo & 0x10) ? H263MI_PICTURE_I : H263MI_PICTURE_P;       // as the reference reads the bit (picture.rs:55-59)
+    if (lo & 0x08) out.options |= OPT_UNRESTRICTED_MOTION_VECTORS;
+    if (lo & 0x04) out.options |= OPT_SYNTAX_BASED_ARITHMETIC_CODING;
+    if (lo & 0x02) out.options |= OPT_ADVANCED_PREDICTION;
+    if (lo & 0x01) out.picture_type = PT_PB;
+    return H263MI_OK;
+}
+
+enum : uint32_t {                                                // PlusPTypeFollower (picture.rs:88-97)
+    FOLLOW_CUSTOM_FORMAT = 1, FOLLOW_CUSTOM_CLOCK = 2, FOLLOW_MV_RANGE = 4, FOLLOW_SLICE_SUBMODE = 8,
+    FOLLOW_REFERENCE_LAYER = 16, FOLLOW_RPS_MODE = 32,
+};
+
+// decode_plusptype (picture.rs:135-268)
+int decode_plusptype(BitReader &r, uint32_t decoder_options, uint32_t previous_options, PictureHeader &out,
+                     uint32_t &followers)
+{
+    int rc;
+    uint32_t ufep, v;
+    followers = 0;
+    RD(3, ufep);
+    if (ufep > 1) return H263MI_ERR_INVALID_PLUS_PTYPE;
+    out.has_opptype = ufep == 1;
+    uint32_t options = 0;
+    out.format = SourceFormat();                                 // None unless OPPTYPE restates it
+    if (out.has_opptype) {
+        RD(18, v);
+        if ((v & 0xF) != 0x8) return H263MI_ERR_INVALID_PLUS_PTYPE;      // H.263 5.1.4.2
+        switch ((v & 0x38000) >> 15) {
+        case 1: out.format = plain_format(SourceFormat::SUB_QCIF); break;
+        case 2: out.format = plain_format(SourceFormat::QCIF); break;
+        case 3: out.format = plain_format(SourceFormat::CIF); break;
+        case 4: out.format = plain_format(SourceFormat::FOUR_CIF); break;
+        case 5: out.format = plain_format(SourceFormat::SIXTEEN_CIF); break;
+        case 6: followers |= FOLLOW_CUSTOM_FORMAT; break;        // format stays None until CPFMT
+        default: out.format = plain_format(SourceFormat::RESERVED); break;      // 0 and 7
+        }
+        if (v & 0x04000) followers |= FOLLOW_CUSTOM_CLOCK;
+        if (v & 0x02000) { options |= OPT_UNRESTRICTED_MOTION_VECTORS; followers |= FOLLOW_MV_RANGE; }
+        if (v & 0x01000) options |= OPT_SYNTAX_BASED_ARITHMETIC_CODING;
+        if (v & 0x00800) options |= OPT_ADVANCED_PREDICTION;
+        if (v & 0x00400) options |= OPT_ADVANCED_INTRA_CODING;
+        if (v & 0x00200) options |= OPT_DEBLOCKING_FILTER;
+        if (v & 0x00100) { options |= OPT_SLICE_STRUCTURED; followers |= FOLLOW_SLICE_SUBMODE; }
+        if (v & 0x00080) { options |= OPT_REFERENCE_PICTURE_SELECTION; followers |= FOLLOW_RPS_MODE; }
+        if (v & 0x00040) options |= OPT_INDEPENDENT_SEGMENT_DECODING;
+        if (v & 0x00020) options |= OPT_ALTERNATIVE_INTER_VLC;
+        if (v & 0x00010) options |= OPT_MODIFIED_QUANTIZATION;
+        if (decoder_options & H263MI_USE_SCALABILITY_MODE) followers |= FOLLOW_REFERENCE_LAYER;
+    } else {
+        options |= previous_options & OPPTYPE_OPTIONS;           // carried forward (picture.rs:233)
+    }
+    RD(9, v);
+    if ((v & 7) != 1) return H263MI_ERR_INVALID_PLUS_PTYPE;      // H.263 5.1.4.3
+    switch ((v & 0x1C0) >> 6) {
+    case 0: out.picture_type = H263MI_PICTURE_I; break;
+    case 1: out.picture_type = H263MI_PICTURE_P; break;
+    case 2: out.picture_type = PT_IMPROVED_PB; break;
+    case 3: out.picture_type = PT_B; break;
+    case 4: out.picture_type = PT_EI; break;
+    case 5: out.picture_type = PT_EP; break;
+    default: out.picture_type = PT_RESERVED; break;
+    }
+    if (v & 0x020) options |= OPT_REFERENCE_PICTURE_RESAMPLING;
+    if (v & 0x010) options |= OPT_REDUCED_RESOLUTION_UPDATE;
+    if (v & 0x008) options |= OPT_ROUNDING_TYPE_ONE;
+    out.options |= options;
+    return H263MI_OK;
+}
+
+// decode_cpm_and_psbi (picture.rs:335-346)
+int decode_cpm_and_psbi(BitReader &r)
+{
+    int rc;
+    uint32_t v;
+    RD(1, v);
+    if (v) RD(2, v);
+    return H263MI_OK;
+}
+
+// decode_cpfmt (picture.rs:349-395)
+int decode_cpfmt(BitReader &r, SourceFormat &f)
+{
+    int rc;
+    uint32_t v;
+    RD(23, v);
+    if (!(v & 0x000200)) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+    f = SourceFormat();
+    f.kind = SourceFormat::EXTENDED;
+    f.par = (uint8_t)((v & 0x780000) >> 19);
+    if (f.par == 0) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+    if (f.par == 15) {
+        uint32_t pw, ph;
+        RD(8, pw);
+        RD(8, ph);
+        if (!pw || !ph) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+        f.par_width = (uint8_t)pw; f.par_height = (uint8_t)ph;
+    }
+    f.width = (uint16_t)((((v & 0x07FC00) >> 10) + 1) * 4);
+    f.height = (uint16_t)((v & 0x0000FF) * 4);                   // the reference masks 8 of the 9 PHI bits
+    return H263MI_OK;
+}
+
+// the standard H.263 header after the (zero) GOB number: picture.rs:662-808
+int decode_standard_header(BitReader &r, uint32_t decoder_options, const ParserContext *prev, PictureHeader &out)
+{
+    int rc;
+    uint32_t v, low_tr;
+    RD(8, low_tr);
+    bool plus = false;
+    if ((rc = decode_ptype(r, out, plus)) != H263MI_OK) return rc;
+    uint32_t followers = 0;
+    bool have_cpm = false;
+    if (plus) {
+        out.has_plusptype = true;
+        if ((rc = decode_plusptype(r, decoder_options, prev && prev->have_last ? prev->last_header_options : 0u, out,
+                                   followers)) != H263MI_OK)
+            return rc;
+        if ((rc = decode_cpm_and_psbi(r)) != H263MI_OK) return rc;
+        have_cpm = true;
+    }
+    if (followers & FOLLOW_CUSTOM_FORMAT)
+        if ((rc = decode_cpfmt(r, out.format)) != H263MI_OK) return rc;
+    bool custom_clock = false;
+    if (followers & FOLLOW_CUSTOM_CLOCK) {                       // decode_cpcfc (picture.rs:398-410)
+        RD(8, v);
+        custom_clock = true;
+    }
+    out.temporal_reference = (uint16_t)low_tr;
+    if (custom_clock) {                                          // ETR (picture.rs:717-723)
+        RD(2, v);
+        out.temporal_reference = (uint16_t)((v << 8) | low_tr);
+    }
+    if (followers & FOLLOW_MV_RANGE) {                           // decode_uui (picture.rs:413-428)
+        RD(1, v);
+        if (v) out.mv_range = 1;
+        else {
+            RD(1, v);
+            if (!v) return H263MI_ERR_INVALID_BITSTREAM;
+            out.mv_range = 2;
+        }
+    }
+    if (followers & FOLLOW_SLICE_SUBMODE) RD(2, v);              // decode_sss
+    if (decoder_options & H263MI_USE_SCALABILITY_MODE) {         // decode_elnum_rlnum (picture.rs:452-471)
+        RD(4, v);
+        if (followers & FOLLOW_REFERENCE_LAYER) RD(4, v);
+    }
+    if (followers & FOLLOW_RPS_MODE) RD(3, v);                   // decode_rpsmf
+    if (out.options & OPT_REFERENCE_PICTURE_SELECTION) {
+        RD(1, v);                                                // decode_trpi (picture.rs:498-513)
+        if (v) RD(10, v);
+        RD(1, v);                                                // decode_bcm (picture.rs:516-537)
+        if (v) return H263MI_ERR_UNIMPLEMENTED_DECODING;
+        RD(1, v);
+        if (!v) return H263MI_ERR_INVALID_BITSTREAM;
+    }
+    // decode_rprp is a stub (picture.rs:540-545); it is reached when the option is set or when the previous
+    // header's Option<SourceFormat> differs from this one's (picture.rs:760-769)
+    if ((out.options & OPT_REFERENCE_PICTURE_RESAMPLING) ||
+        (prev && prev->have_last && prev->last_header_format != out.format))
+        return H263MI_ERR_UNIMPLEMENTED_DECODING;
+    RD(5, v);
+    out.quantizer = (uint8_t)v;
+    if (!have_cpm && (rc = decode_cpm_and_psbi(r)) != H263MI_OK) return rc;
+    if (out.picture_type == PT_PB || out.picture_type == PT_IMPROVED_PB) {
+        RD(custom_clock ? 5u : 3u, v);                           // decode_trb (picture.rs:548-559)
+        RD(2, v);                                                // decode_dbquant
+    }
+    return decode_pei(r, out.extra);
+}
+#undef RD
+}  // namespace
+
+int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserContext *prev, PictureHeader &out,
+                          bool &is_picture)
 {
     const size_t checkpoint = r.position();          // with_transaction_union (picture.rs:619)
     out = PictureHeader();
@@ -228,54 +525,21 @@ int decode_picture_header(BitReader &r, uint32_t decoder_options, PictureHeader 
         if ((rc = r.recognize_start_code(false, skipped)) != H263MI_OK) break;
         if (skipped < 0) { rc = H263MI_ERR_MIDDLE_OF_BITSTREAM; break; }
         if ((rc = r.skip_bits(17 + (uint32_t)skipped)) != H263MI_OK) break;
-        uint32_t gob_id, v;
+        uint32_t gob_id;
         if ((rc = r.read_bits(5, gob_id)) != H263MI_OK) break;
-        if (!(decoder_options & H263MI_SORENSON_SPARK_BITSTREAM)) {
-            // standard H.263 PTYPE / PLUSPTYPE paths: SURVEY section 8 row f-4, not built yet
-            rc = H263MI_ERR_UNIMPLEMENTED_DECODING;
-            break;
-        }
-        out.version = (int)gob_id;                   // "Sorenson abuses the GOB ID as a version field"
-        if ((rc = r.read_u8(v)) != H263MI_OK) break;
-        out.temporal_reference = (uint16_t)v;
-        // decode_sorenson_ptype (picture.rs:271-327)
-        uint32_t fmt;
-        if ((rc = r.read_bits(3, fmt)) != H263MI_OK) break;
-        out.format_valid = true;
-        switch (fmt) {
-        case 0:
-        case 1: {
-            const uint32_t n = fmt == 0 ? 8 : 16;
-            uint32_t w, h;
-            if ((rc = r.read_bits(n, w)) != H263MI_OK) break;
-            if ((rc = r.read_bits(n, h)) != H263MI_OK) break;
-            out.width = (uint16_t)w; out.height = (uint16_t)h;
-            break;
-        }
-        case 2: out.width = 352; out.height = 288; break;     // FullCif     (types.rs:168-180)
-        case 3: out.width = 176; out.height = 144; break;     // QuarterCif
-        case 4: out.width = 128; out.height = 96; break;      // SubQcif
-        case 5: out.width = 320; out.height = 240; break;
-        case 6: out.width = 160; out.height = 120; break;
-        default: out.format_valid = false; break;              // SourceFormat::Reserved
+        if (decoder_options & H263MI_SORENSON_SPARK_BITSTREAM) {
+            out.version = (int)gob_id;               // "Sorenson abuses the GOB ID as a version field"
+            rc = decode_sorenson_header(r, out);
+        } else if (gob_id != 0) {
+            break;                                   // a GOB header: Ok(None), position restored below
+        } else {
+            rc = decode_standard_header(r, decoder_options, prev, out);
         }
         if (rc != H263MI_OK) break;
-        if ((rc = r.read_bits(2, v)) != H263MI_OK) break;
-        out.picture_type = (uint8_t)v;
-        if ((rc = r.read_bits(1, v)) != H263MI_OK) break;
-        out.use_deblocker = v == 1;
-        if ((rc = r.read_bits(5, v)) != H263MI_OK) break;
-        out.quantizer = (uint8_t)v;
-        for (;;) {                                   // decode_pei (picture.rs:577-596)
-            if ((rc = r.read_bits(1, v)) != H263MI_OK) break;
-            if (!v) break;
-            if ((rc = r.read_u8(v)) != H263MI_OK) break;
-            out.extra.push_back((uint8_t)v);
-        }
-        if (rc != H263MI_OK) break;
+        out.format_valid = out.format.dimensions(out.width, out.height);
         is_picture = true;
     } while (0);
-    if (rc != H263MI_OK) r.rollback(checkpoint);
+    if (rc != H263MI_OK || !is_picture) r.rollback(checkpoint);
     return rc;
 }
 
@@ -326,33 +590,77 @@ Mv predict_candidate(const std::vector<Mv> &pv /* 4 per MB */, const Mv cur[4], 
     return Mv{median3(mv1.x, mv2.x, mv3.x), median3(mv1.y, mv2.y, mv3.y)};
 }
 
-// halfpel_decode (mvd_pred.rs:70-117) for the cases a Sorenson stream can reach: no
-// UNRESTRICTED_MOTION_VECTORS option is ever set there, so the range is the standard [-32, 32) half-pels
-int16_t halfpel_decode(int16_t predictor, int16_t mvd)
+// halfpel_decode (mvd_pred.rs:70-117).  Ranges are HalfPel::STANDARD_RANGE .. EXTENDED_RANGE_BEYONDCIF
+// (types.rs:700-704); `dim` is the picture width for x and the height for y.
+int16_t halfpel_decode(uint32_t running_options, const PictureHeader &hdr, int dim, int16_t predictor, int16_t mvd, bool is_x)
 {
+    int range = 32;
     int out = mvd + predictor;
-    if (!(-32 <= out && out < 32)) {
+    const bool umv = (running_options & OPT_UNRESTRICTED_MOTION_VECTORS) != 0;
+    if (umv && !hdr.has_plusptype) {
+        if (-32 <= predictor && predictor < 32) return (int16_t)out;
+        range = 64;
+    } else if (umv && hdr.mv_range == 1) {
+        if (is_x) range = dim <= 352 ? 64 : (356 <= dim && dim <= 704) ? 128 : (708 <= dim && dim <= 1408) ? 256 : dim >= 1412 ? 512 : 64;
+        else range = dim <= 288 ? 64 : (292 <= dim && dim <= 576) ? 128 : dim >= 580 ? 256 : 64;
+    }
+    if (!(-range <= out && out < range)) {
         const int inv = mvd > 0 ? mvd - 64 : (mvd < 0 ? mvd + 64 : mvd);     // HalfPel::invert (types.rs:736-742)
         out = inv + predictor;
     }
     return (int16_t)out;
+}
+
+// decode_gob (gob.rs:20-41), as used by the resynchronisation of state.rs:387-408.  Returns true when the
+// macroblock loop should stop (end of picture); false with rc set when the decode fails.
+bool resync_ends_picture(BitReader &r, int &rc)
+{
+    int skipped;
+    rc = r.recognize_start_code(false, skipped);
+    if (rc == kEof) { rc = H263MI_OK; return true; }                 // "Treat EOF/GOB errors as end of picture"
+    if (rc != H263MI_OK) return false;
+    if (skipped < 0) return true;                                    // InvalidGobHeader: a GOB error, ends the picture
+    BitReader look = r;                                              // with_transaction_union: nothing is consumed
+    uint32_t gob_id = 0;
+    if (look.skip_bits(17 + (uint32_t)skipped) != H263MI_OK || look.read_bits(5, gob_id) != H263MI_OK) return true;
+    if (gob_id == 0 || gob_id == 15) return true;                    // picture start code (or 15, as the reference has it)
+    rc = H263MI_ERR_UNIMPLEMENTED_DECODING;                          // real GOB headers are a stub in the reference
+    return false;
 }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // whole picture: state.rs:138-427 up to the cut line
 // ---------------------------------------------------------------------------------------------------
-int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, ParsedPicture &out)
+int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, const ParserContext *ctx, ParsedPicture &out)
 {
     out = ParsedPicture();
     BitReader r(data, len);
     PictureHeader hdr;
     bool is_picture = false;
-    int rc = decode_picture_header(r, decoder_options, hdr, is_picture);
+    int rc = decode_picture_header(r, decoder_options, ctx, hdr, is_picture);
     if (rc != H263MI_OK) return rc;
     if (!is_picture) return H263MI_ERR_MIDDLE_OF_BITSTREAM;                    // state.rs:143-145
-    if (!hdr.format_valid || !hdr.width || !hdr.height) return H263MI_ERR_PICTURE_FORMAT_INVALID;   // state.rs:169-171
     const bool sorenson = (decoder_options & H263MI_SORENSON_SPARK_BITSTREAM) != 0;
+
+    // state.rs:147-155.  `self.running_options` is never written by the reference, so it is the empty set:
+    // OPPTYPE options only take effect in a picture that carries OPPTYPE itself, and the UMV / SAC / AP bits of
+    // a plain PTYPE never do.
+    const uint32_t state_running_options = 0;
+    uint32_t running_options;
+    if (hdr.has_plusptype && hdr.has_opptype) running_options = hdr.options;
+    else if (hdr.has_plusptype) running_options = (hdr.options & ~OPPTYPE_OPTIONS) | (state_running_options & OPPTYPE_OPTIONS);
+    else running_options = (hdr.options & ~OPPTYPE_OPTIONS & ~MPPTYPE_OPTIONS) | (state_running_options & (OPPTYPE_OPTIONS | MPPTYPE_OPTIONS));
+
+    // state.rs:157-171: the format of this picture
+    SourceFormat format = hdr.format;
+    if (format.kind == SourceFormat::NONE) {
+        if (hdr.picture_type == H263MI_PICTURE_I) return H263MI_ERR_PICTURE_FORMAT_MISSING;
+        if (!ctx || !ctx->have_last) return H263MI_ERR_PICTURE_FORMAT_MISSING;
+        format = ctx->last_format;
+    }
+    if (!format.dimensions(hdr.width, hdr.height)) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+    if (!hdr.width || !hdr.height) return H263MI_ERR_PICTURE_FORMAT_INVALID;   // no picture to hold (back-end limit)
 
     out.desc.width = hdr.width;
     out.desc.height = hdr.height;
@@ -360,6 +668,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, Par
     out.desc.pquant = hdr.quantizer;
     out.desc.use_deblocker = hdr.use_deblocker ? 1 : 0;
     out.desc.temporal_reference = hdr.temporal_reference;
+    out.next.have_last = true;
+    out.next.last_header_format = hdr.format;
+    out.next.last_header_options = hdr.options;
+    out.next.last_format = format;
 
     const size_t mb_per_line = (hdr.width + 15u) / 16u, mb_height = (hdr.height + 15u) / 16u;   // state.rs:173-174
     const size_t total = mb_per_line * mb_height;
@@ -391,6 +703,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, Par
             if ((mrc = cbpy_table().decode(r, h)) != H263MI_OK) break;
             if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS; break; }
             luma = intra ? h.v0 : (~h.v0 & 0xf);                     // macroblock.rs:479-489
+            if (running_options & OPT_MODIFIED_QUANTIZATION) { mrc = H263MI_ERR_UNIMPLEMENTED_DECODING; break; }   // macroblock.rs:497-498
             if (mb_type == H263MI_MB_INTER_Q || mb_type == H263MI_MB_INTRA_Q || mb_type == H263MI_MB_INTER4V_Q) {
                 if ((mrc = r.read_bits(2, v)) != H263MI_OK) break;   // decode_dquant (macroblock.rs:257-271)
                 static const int kDquant[4] = {-1, -2, 1, 2};
@@ -400,6 +713,13 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, Par
             if (!intra) {
                 const int n_mv = (mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q) ? 4 : 1;
                 for (int k = 0; k < n_mv && mrc == H263MI_OK; k++) {
+                    if ((running_options & OPT_UNRESTRICTED_MOTION_VECTORS) && hdr.has_plusptype) {
+                        int ux, uy;                                  // Annex D vectors (macroblock.rs:424-430)
+                        if ((mrc = r.read_umv(ux)) != H263MI_OK) break;
+                        if ((mrc = r.read_umv(uy)) != H263MI_OK) break;
+                        mvd[k] = Mv{(int16_t)ux, (int16_t)uy};
+                        continue;
+                    }
                     VlcHit hx, hy;                                   // decode_motion_vector (macroblock.rs:414-438)
                     if ((mrc = mvd_table().decode(r, hx)) != H263MI_OK) break;
                     if (!hx.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
@@ -411,8 +731,13 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, Par
         } while (0);
         if (mrc != H263MI_OK) {
             r.rollback(mb_checkpoint);
-            // state.rs:387-412: macroblock errors would resynchronise to the next GOB in standard H.263 (not in
-            // Sorenson mode); EOF ends the picture; anything else fails the decode
+            // state.rs:387-412: in standard H.263 a macroblock header error looks for the next GOB or picture
+            // start code (never in Sorenson mode); EOF ends the picture; anything else fails the decode
+            if (!sorenson && (mrc == H263MI_ERR_INVALID_MACROBLOCK_HEADER || mrc == H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS)) {
+                int grc = H263MI_OK;
+                if (resync_ends_picture(r, grc)) break;
+                return grc;
+            }
             if (mrc == kEof) break;
             return mrc;
         }
@@ -433,7 +758,8 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, Par
                 const bool four = mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q;
                 for (int k = 0; k < (four ? 4 : 1); k++) {
                     const Mv pred = predict_candidate(predictor_vectors, motion_vectors, mb_per_line, k);
-                    motion_vectors[k] = Mv{halfpel_decode(pred.x, mvd[k].x), halfpel_decode(pred.y, mvd[k].y)};
+                    motion_vectors[k] = Mv{halfpel_decode(running_options, hdr, hdr.width, pred.x, mvd[k].x, true),
+                                           halfpel_decode(running_options, hdr, hdr.height, pred.y, mvd[k].y, false)};
                 }
                 if (!four) motion_vectors[1] = motion_vectors[2] = motion_vectors[3] = motion_vectors[0];
             }

@@ -1,7 +1,7 @@
 // bitstream.hpp -- host-side Sorenson Spark / H.263 bitstream parser that emits macroblock records
-// (SURVEY section 8 row f-1).  This is the serial half of H263State::decode_next_picture
+// (SURVEY section 8 rows f-1 and f-4).  This is the serial half of H263State::decode_next_picture
 // (h263/src/decoder/state.rs:138-427): bit reader (parser/reader.rs), picture layer (parser/picture.rs:
-// 611-661, 271-327, 577-596), macroblock layer (parser/macroblock.rs:445-549), block layer
+// 21-661), GOB resynchronisation stub (parser/gob.rs:20-41), macroblock layer (parser/macroblock.rs:445-549), block layer
 // (parser/block.rs:670-755) and motion vector prediction (decoder/cpu/mvd_pred.rs:27-134).  Instead
 // of DecodedDctBlock enums it writes the h263mi_mb_record array + dense coefficient blocks that cross
 // the C ABI; no pixel arithmetic happens here.
@@ -40,6 +40,8 @@ public:
     int read_u8(uint32_t &out) { return read_bits(8, out); }
     // recognize_start_code (reader.rs:244-262): *skipped = bits in front of the start code, or -1 for None
     int recognize_start_code(bool in_error, int &skipped) const;
+    // read_umv (reader.rs:298-324): unrestricted motion vector component, half-pel units
+    int read_umv(int &out);
 
 private:
     const uint8_t *p_;
@@ -84,19 +86,88 @@ struct ParsedBlock {
 };
 int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, ParsedBlock &out);
 
-// ---- picture header (parser/picture.rs:611-661, Sorenson branch) -------------------------------------
+// ---- picture header (parser/picture.rs:21-661: PTYPE, PLUSPTYPE and the Sorenson variant) ----------------
+// PictureOption (types.rs:195-216)
+enum : uint32_t {
+    OPT_USE_SPLIT_SCREEN = 1u << 0,
+    OPT_USE_DOCUMENT_CAMERA = 1u << 1,
+    OPT_RELEASE_FULL_PICTURE_FREEZE = 1u << 2,
+    OPT_UNRESTRICTED_MOTION_VECTORS = 1u << 3,
+    OPT_SYNTAX_BASED_ARITHMETIC_CODING = 1u << 4,
+    OPT_ADVANCED_PREDICTION = 1u << 5,
+    OPT_ADVANCED_INTRA_CODING = 1u << 6,
+    OPT_DEBLOCKING_FILTER = 1u << 7,
+    OPT_SLICE_STRUCTURED = 1u << 8,
+    OPT_REFERENCE_PICTURE_SELECTION = 1u << 9,
+    OPT_INDEPENDENT_SEGMENT_DECODING = 1u << 10,
+    OPT_ALTERNATIVE_INTER_VLC = 1u << 11,
+    OPT_MODIFIED_QUANTIZATION = 1u << 12,
+    OPT_REFERENCE_PICTURE_RESAMPLING = 1u << 13,
+    OPT_REDUCED_RESOLUTION_UPDATE = 1u << 14,
+    OPT_ROUNDING_TYPE_ONE = 1u << 15,
+    OPT_USE_DEBLOCKER = 1u << 16,            // Sorenson only
+};
+// types.rs:223-240
+constexpr uint32_t OPPTYPE_OPTIONS = OPT_UNRESTRICTED_MOTION_VECTORS | OPT_SYNTAX_BASED_ARITHMETIC_CODING |
+                                     OPT_ADVANCED_PREDICTION | OPT_ADVANCED_INTRA_CODING | OPT_DEBLOCKING_FILTER |
+                                     OPT_SLICE_STRUCTURED | OPT_REFERENCE_PICTURE_SELECTION |
+                                     OPT_INDEPENDENT_SEGMENT_DECODING | OPT_ALTERNATIVE_INTER_VLC |
+                                     OPT_MODIFIED_QUANTIZATION;
+constexpr uint32_t MPPTYPE_OPTIONS = OPT_REFERENCE_PICTURE_RESAMPLING | OPT_REDUCED_RESOLUTION_UPDATE | OPT_ROUNDING_TYPE_ONE;
+
+// SourceFormat (types.rs:120-181) with Option<> folded in; equality is the derived PartialEq of the reference
+// (Extended compares aspect ratio and both indications, SubQcif != Extended(128x96))
+struct SourceFormat {
+    enum Kind : uint8_t { NONE = 0, SUB_QCIF, QCIF, CIF, FOUR_CIF, SIXTEEN_CIF, RESERVED, EXTENDED };
+    uint8_t kind = NONE;
+    uint8_t par = 0;                       // PixelAspectRatio: 1 square .. 5 40:33, 15 extended, other = Reserved(par)
+    uint8_t par_width = 0, par_height = 0; // EPAR
+    uint16_t width = 0, height = 0;        // picture_width_indication / picture_height_indication
+    bool operator==(const SourceFormat &o) const
+    {
+        if (kind != o.kind) return false;
+        if (kind != EXTENDED) return true;
+        if (par != o.par || width != o.width || height != o.height) return false;
+        return par != 15 || (par_width == o.par_width && par_height == o.par_height);
+    }
+    bool operator!=(const SourceFormat &o) const { return !(*this == o); }
+    // into_width_and_height (types.rs:168-180); false for Reserved (and for NONE)
+    bool dimensions(uint16_t &w, uint16_t &h) const;
+};
+
+// PictureTypeCode (types.rs:251-288) as carried in h263mi_picture_desc.picture_type: 0..3 are the values of
+// the Sorenson 2-bit field, the rest only exist in standard H.263 headers
+enum : uint8_t { PT_PB = H263MI_PICTURE_PB, PT_IMPROVED_PB = H263MI_PICTURE_IMPROVED_PB, PT_B = H263MI_PICTURE_B,
+                 PT_EI = H263MI_PICTURE_EI, PT_EP = H263MI_PICTURE_EP, PT_RESERVED = H263MI_PICTURE_RESERVED };
+
 struct PictureHeader {
-    int version = 0;                       // Sorenson keeps it where H.263 has the GOB number
+    int version = -1;                      // Sorenson keeps it where H.263 has the GOB number; -1 = None
     uint16_t temporal_reference = 0;
-    uint16_t width = 0, height = 0;
-    bool format_valid = false;             // SourceFormat::Reserved has no dimensions
-    uint8_t picture_type = 0;              // 0 I, 1 P, 2 disposable P, 3 reserved
-    bool use_deblocker = false;
+    SourceFormat format;                   // Option<SourceFormat>: kind NONE when the header restates none
+    uint16_t width = 0, height = 0;        // of `format`, when it has dimensions
+    bool format_valid = false;
+    uint32_t options = 0;                  // PictureOption bits
+    bool has_plusptype = false, has_opptype = false;
+    uint8_t picture_type = 0;              // 0 I, 1 P, 2 disposable P, 3 reserved (Sorenson), PT_* above
+    bool use_deblocker = false;            // OPT_USE_DEBLOCKER
+    uint8_t mv_range = 0;                  // MotionVectorRange: 0 None, 1 Extended, 2 Unlimited
     uint8_t quantizer = 0;
     std::vector<uint8_t> extra;            // PEI / PSUPP bytes
 };
-// decode_picture(reader, options, prev): H263MI_OK with *is_picture = false when a GOB start was found
-int decode_picture_header(BitReader &r, uint32_t decoder_options, PictureHeader &out, bool &is_picture);
+
+// What decode_next_picture takes from the state about the last decoded picture (state.rs:143-167):
+// its header (`previous_picture`) and its resolved format.
+struct ParserContext {
+    bool have_last = false;
+    SourceFormat last_header_format;       // last_picture.as_header().format
+    uint32_t last_header_options = 0;      // last_picture.as_header().options
+    SourceFormat last_format;              // last_picture.format()
+};
+
+// decode_picture(reader, options, previous_picture): H263MI_OK with *is_picture = false when a GOB start
+// was found.  `prev` may be null (no previous picture).
+int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserContext *prev, PictureHeader &out,
+                          bool &is_picture);
 
 // ---- whole picture -> records (state.rs:138-427) ------------------------------------------------------
 struct ParsedPicture {
@@ -104,10 +175,11 @@ struct ParsedPicture {
     std::vector<h263mi_mb_record> mbs;     // the macroblocks present in the bitstream (<= mbw*mbh)
     std::vector<int16_t> coeffs;           // 64 per coded block, raster order
     size_t bits_consumed = 0;
+    ParserContext next;                    // the context once this picture has been decoded successfully
 };
 // Returns H263MI_OK or the error the reference's decode_next_picture would return before touching any
-// pixel.  `have_last_format`: the last decoded picture's size, used when a header carries no format.
-int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, ParsedPicture &out);
+// pixel.  `ctx`: the last decoded picture (null = none), needed by standard H.263 headers that carry no format.
+int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, const ParserContext *ctx, ParsedPicture &out);
 
 }  // namespace bits
 }  // namespace h263mi

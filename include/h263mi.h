@@ -111,6 +111,17 @@ typedef struct h263mi_mb_record {
 #define H263MI_PICTURE_I 0   /* PictureTypeCode::IFrame: clears the reference (state.rs:464-470) */
 #define H263MI_PICTURE_P 1   /* PFrame */
 #define H263MI_PICTURE_DISPOSABLE_P 2 /* does not become the reference (state.rs:474-480) */
+/* The remaining PictureTypeCode values (types.rs:251-288) only come out of picture headers: 3 = the reserved code of
+ * the Sorenson 2-bit field, the others exist in ITU-T H.263 PTYPE / MPPTYPE only.  The macroblock layer of the
+ * reference decodes I and P pictures; a coded macroblock in any other type is H263MI_ERR_UNIMPLEMENTED_DECODING
+ * (macroblock.rs:461-465).  For h263mi_submit_picture every type but I predicts from the reference picture. */
+#define H263MI_PICTURE_RESERVED_SORENSON 3
+#define H263MI_PICTURE_PB 4
+#define H263MI_PICTURE_IMPROVED_PB 5
+#define H263MI_PICTURE_B 6
+#define H263MI_PICTURE_EI 7
+#define H263MI_PICTURE_EP 8
+#define H263MI_PICTURE_RESERVED 9
 typedef struct h263mi_picture_desc {
     uint16_t width, height;        /* SourceFormat::into_width_and_height (state.rs:169-171) */
     uint8_t  picture_type;
@@ -162,14 +173,18 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc,
 /*
  * H263State::decode_next_picture(reader)  state.rs:138-141, over a byte buffer holding
  * one coded picture (Ruffle hands one FLV video tag per reader).  `*consumed` receives the
- * bytes used.  The serial parse runs on the host (h263-rs_amd/host/bitstream.cpp: Sorenson Spark headers,
- * MCBPC/CBPY/MVD/TCOEF tables, motion vector prediction) and feeds h263mi_submit_picture.  Standard H.263
- * (non-Sorenson) headers return H263MI_ERR_UNIMPLEMENTED_DECODING.
+ * bytes used.  The serial parse runs on the host (h263-rs_amd/host/bitstream.cpp: Sorenson Spark and ITU-T H.263
+ * PTYPE / PLUSPTYPE headers, MCBPC/CBPY/MVD/TCOEF tables, Annex D vectors, motion vector prediction, the
+ * start-code resynchronisation of state.rs:387-408) and feeds h263mi_submit_picture.  What the reference leaves
+ * unimplemented (GOB headers, PB / B / EI / EP macroblocks, Annex T, reference picture resampling, back-channel
+ * messages) returns H263MI_ERR_UNIMPLEMENTED_DECODING here too.  On any error the state -- including what it
+ * remembers of the last picture header -- is unchanged.
  */
 int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len, size_t *consumed);
 /* H263State::parse_picture(reader, previous_picture)  state.rs:102-111: header peek only (frame dependency
- * queries); fills the fields of h263mi_picture_desc from the picture header.  H263MI_ERR_MIDDLE_OF_BITSTREAM when the
- * data does not start with a picture start code. */
+ * queries); fills the fields of h263mi_picture_desc from the picture header (width = height = 0 when the header
+ * restates no format).  `previous_picture` is the state's last decoded picture.  H263MI_ERR_MIDDLE_OF_BITSTREAM when
+ * the data does not start with a picture start code. */
 int h263mi_parse_picture_header(const h263mi_state *s, const uint8_t *data, size_t len, h263mi_picture_desc *out);
 
 /* DecodedPicture accessors (picture.rs:61-142) of get_last_picture() (state.rs:61-67). */

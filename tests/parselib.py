@@ -31,7 +31,11 @@ def lib():
         L.pt_reader_script.restype = None
         L.pt_parse_picture.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(PictureDesc), C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
-                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
+        L.pt_parse_header.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p]
+        L.pt_read_umv.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pt_read_umv.restype = None
+        L.pt_context_reset.restype = None
         _lib = L
     return _lib
 
@@ -66,12 +70,35 @@ def reader_script(data, ops):
     return [(int(r), int(v)) for r, v in res]
 
 
-def parse_picture(data, options=1, cap_mbs=20000, cap_blocks=120000):
+def context_reset():
+    """forget the last decoded picture (a fresh H263State)"""
+    lib().pt_context_reset()
+
+
+HEADER_FIELDS = ("rc is_picture picture_type width height format_kind options has_plusptype has_opptype mv_range "
+                 "quantizer temporal_reference n_extra bits_used").split()
+
+
+def parse_header(data, options=0, use_context=False):
+    a, ln = _bytes(data)
+    out = np.zeros(len(HEADER_FIELDS), np.int32)
+    lib().pt_parse_header(a.ctypes.data, ln, options, int(use_context), out.ctypes.data)
+    return dict(zip(HEADER_FIELDS, (int(v) for v in out)))
+
+
+def read_umv(data):
+    a, ln = _bytes(data)
+    out = np.zeros(3, np.int32)
+    lib().pt_read_umv(a.ctypes.data, ln, out.ctypes.data)
+    return tuple(int(v) for v in out)
+
+
+def parse_picture(data, options=1, cap_mbs=20000, cap_blocks=120000, use_context=False):
     a, ln = _bytes(data)
     d = PictureDesc()
     mbs = np.zeros(cap_mbs, MB_RECORD_DTYPE)
     co = np.zeros((cap_blocks, 64), np.int16)
     n_mbs, n_blocks, bits = C.c_size_t(), C.c_size_t(), C.c_size_t()
     rc = lib().pt_parse_picture(a.ctypes.data, ln, options, C.byref(d), mbs.ctypes.data, cap_mbs, co.ctypes.data,
-                                cap_blocks, C.byref(n_mbs), C.byref(n_blocks), C.byref(bits))
+                                cap_blocks, C.byref(n_mbs), C.byref(n_blocks), C.byref(bits), int(use_context))
     return rc, d, mbs[:n_mbs.value].copy(), co[:n_blocks.value].copy(), bits.value

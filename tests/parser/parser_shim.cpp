@@ -63,17 +63,46 @@ void pt_reader_script(const uint8_t *data, size_t len, int n_ops, const int32_t 
 }
 
 // whole picture -> records.  Returns rc; *n_mbs / *n_blocks the counts (capacity checked).
+// ctx (in/out, may be null): the parser's view of the last decoded picture, as 16 opaque bytes + validity --
+// updated when the parse succeeds, like the state commit of decode_next_picture.
+static ParserContext g_ctx;
+void pt_context_reset() { g_ctx = ParserContext(); }
+
 int pt_parse_picture(const uint8_t *data, size_t len, uint32_t options, h263mi_picture_desc *desc, h263mi_mb_record *mbs,
-                     size_t cap_mbs, int16_t *coeffs, size_t cap_blocks, size_t *n_mbs, size_t *n_blocks, size_t *bits)
+                     size_t cap_mbs, int16_t *coeffs, size_t cap_blocks, size_t *n_mbs, size_t *n_blocks, size_t *bits,
+                     int use_context)
 {
     ParsedPicture p;
-    int rc = parse_picture(data, len, options, p);
+    int rc = parse_picture(data, len, options, use_context ? &g_ctx : nullptr, p);
     *n_mbs = p.mbs.size(); *n_blocks = p.coeffs.size() / 64; *bits = p.bits_consumed;
     if (rc != H263MI_OK) return rc;
     *desc = p.desc;
     if (p.mbs.size() > cap_mbs || p.coeffs.size() / 64 > cap_blocks) return H263MI_ERR_INVALID_ARGUMENT;
     if (!p.mbs.empty()) memcpy(mbs, p.mbs.data(), p.mbs.size() * sizeof(h263mi_mb_record));
     if (!p.coeffs.empty()) memcpy(coeffs, p.coeffs.data(), p.coeffs.size() * sizeof(int16_t));
+    if (use_context) g_ctx = p.next;
     return rc;
+}
+
+// picture header only.  out: [rc, is_picture, picture_type, width, height, format_kind, options, has_plusptype,
+// has_opptype, mv_range, quantizer, temporal_reference, n_extra, bits_used]
+int pt_parse_header(const uint8_t *data, size_t len, uint32_t options, int use_context, int32_t *out)
+{
+    BitReader r(data, len);
+    PictureHeader h;
+    bool is_picture = false;
+    int rc = decode_picture_header(r, options, use_context ? &g_ctx : nullptr, h, is_picture);
+    out[0] = rc; out[1] = is_picture; out[2] = h.picture_type; out[3] = h.width; out[4] = h.height; out[5] = h.format.kind;
+    out[6] = (int32_t)h.options; out[7] = h.has_plusptype; out[8] = h.has_opptype; out[9] = h.mv_range; out[10] = h.quantizer;
+    out[11] = h.temporal_reference; out[12] = (int32_t)h.extra.size(); out[13] = (int32_t)r.position();
+    return rc;
+}
+
+// read_umv: out = [rc, value, bits_used]
+void pt_read_umv(const uint8_t *data, size_t len, int32_t *out)
+{
+    BitReader r(data, len);
+    int v = 0;
+    out[0] = r.read_umv(v); out[1] = v; out[2] = (int32_t)r.position();
 }
 }

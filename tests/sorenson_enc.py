@@ -1,4 +1,4 @@
-"""A tiny Sorenson Spark (H.263 flavour of FLV1, version 1) bitstream WRITER for fixtures.
+"""A tiny Sorenson Spark (H.263 flavour of FLV1, version 1) and baseline ITU-T H.263 bitstream WRITER for fixtures.
 
 Test infrastructure: the reference ships no sample streams, so end-to-end tests of
 decode_next_picture(bytes) need pictures serialised from known macroblock records.  The layout follows
@@ -94,7 +94,18 @@ def mvd_for(mv, pred):
     return d
 
 
-def write_block(bw, coeff, intra, intradc, coded, extra_events=()):
+def write_umv(bw, v):
+    """Table D.3/H.263 as read by reader.rs:298-324: '1' = 0, else 0, (mantissa bit, 1)*, (sign, 0)."""
+    if v == 0:
+        bw.put(1, 1)
+        return
+    bw.put(0, 1)
+    for b in format(abs(v), "b")[1:]:
+        bw.put(int(b), 1); bw.put(1, 1)
+    bw.put(1 if v < 0 else 0, 1); bw.put(0, 1)
+
+
+def write_block(bw, coeff, intra, intradc, coded, extra_events=(), standard=False):
     if intra:
         bw.put(int(intradc), 8)
     if not coded:
@@ -115,34 +126,112 @@ def write_block(bw, coeff, intra, intradc, coded, extra_events=()):
             bw.put(1 if lv < 0 else 0, 1)
         else:
             bw.code(TCOEF_ESCAPE)
-            if -64 <= lv <= 63:
+            if standard:                      # H.263 5.4.2: LAST, RUN, 8-bit LEVEL (block.rs:699)
+                assert -128 <= lv <= 127
+                bw.put(is_last, 1); bw.put(run, 6); bw.put(lv, 8)
+            elif -64 <= lv <= 63:
                 bw.put(0, 1); bw.put(is_last, 1); bw.put(run, 6); bw.put(lv, 7)
             else:
                 assert -1024 <= lv <= 1023
                 bw.put(1, 1); bw.put(is_last, 1); bw.put(run, 6); bw.put(lv, 11)
 
 
+STD_FORMATS = {(128, 96): 1, (176, 144): 2, (352, 288): 3, (704, 576): 4, (1408, 1152): 5}
+# OPPTYPE option bits as picture.rs:176-226 reads them (18-bit field)
+OPP_CUSTOM_PCF, OPP_UMV, OPP_SAC, OPP_AP, OPP_AIC, OPP_DF, OPP_SS, OPP_RPS, OPP_ISD, OPP_AIV, OPP_MQ = (
+    0x04000, 0x02000, 0x01000, 0x00800, 0x00400, 0x00200, 0x00100, 0x00080, 0x00040, 0x00020, 0x00010)
+
+
+def write_standard_header(bw, width, height, picture_type, pquant, temporal_reference=0, plus=False, ufep=1,
+                          opptype=0, mpptype_flags=0, ptype_low=0, ptype_high_flags=0, uui="1", par=1, epar=(1, 1),
+                          custom_format=None, pei=(), cpm=0, ptype_format=None, sss=0, rpsmf=4, etr=0, pb=False,
+                          scalability=False, mpp_type=None):
+    """ITU-T H.263 5.1 picture header in the bit order parser/picture.rs:662-808 consumes.
+
+    picture_type: 0 I, 1 P.  plus: PLUSPTYPE (source format 111).  ptype_low: UMV 8 | SAC 4 | AP 2 bits of PTYPE.
+    custom_format: None = use the standard format code of (width, height); True = CPFMT."""
+    bw.put(1, 17)
+    bw.put(0, 5)                                      # GOB number 0 = picture start code
+    bw.put(temporal_reference & 0xff, 8)
+    bw.put(2, 2)                                      # "10"
+    bw.put(ptype_high_flags, 3)                       # split screen, document camera, freeze release
+    if not plus:
+        bw.put(STD_FORMATS[(width, height)] if ptype_format is None else ptype_format, 3)
+        # the reference takes bit 0x10 of the low PTYPE bits SET as an I picture (picture.rs:55-59)
+        bw.put((0x10 if picture_type == 0 else 0) | ptype_low | (1 if pb else 0), 5)
+    else:
+        bw.put(7, 3)
+        bw.put(ufep, 3)
+        custom = custom_format or (width, height) not in STD_FORMATS
+        if ufep == 1:
+            fmt = 6 if custom else STD_FORMATS[(width, height)]
+            bw.put((fmt << 15) | opptype | 0x8, 18)
+        t = mpp_type if mpp_type is not None else picture_type
+        bw.put((t << 6) | mpptype_flags | 1, 9)
+        bw.put(cpm, 1)
+        if cpm:
+            bw.put(0, 2)
+        if ufep == 1 and custom:
+            bw.put((par << 19) | ((width // 4 - 1) << 10) | 0x200 | (height // 4), 23)
+            if par == 15:
+                bw.put(epar[0], 8); bw.put(epar[1], 8)
+        if ufep == 1 and (opptype & OPP_CUSTOM_PCF):
+            bw.put(0x21, 8)                           # CPCFC
+            bw.put(etr, 2)                            # ETR
+        if ufep == 1 and (opptype & OPP_UMV):
+            bw.code(uui)
+        if ufep == 1 and (opptype & OPP_SS):
+            bw.put(sss, 2)
+        if scalability:
+            bw.put(1, 4)
+            if ufep == 1:
+                bw.put(0, 4)
+        if ufep == 1 and (opptype & OPP_RPS):
+            bw.put(rpsmf, 3)
+            bw.put(0, 1)                              # TRPI
+            bw.code("01")                             # BCI
+    bw.put(pquant, 5)
+    if not plus:
+        bw.put(cpm, 1)
+        if cpm:
+            bw.put(0, 2)
+    if pb or (plus and mpp_type == 2):
+        bw.put(0, 5 if (plus and ufep == 1 and (opptype & OPP_CUSTOM_PCF)) else 3)
+        bw.put(0, 2)
+    for byte in pei:
+        bw.put(1, 1); bw.put(byte, 8)
+    bw.put(0, 1)
+
+
 def encode_picture(width, height, picture_type, pquant, mbs, coeffs, temporal_reference=0, deblock_flag=0,
-                   version=1, uncoded_as_cod=True, stuffing_every=0, overflow_blocks=()):
+                   version=1, uncoded_as_cod=True, stuffing_every=0, overflow_blocks=(), standard=None):
+    """standard: None = Sorenson Spark; a dict of write_standard_header keyword arguments = ITU-T H.263 (8-bit
+    escape levels; Annex D vectors when the dict has umv=True)."""
     """records (mb_type, quant, cbp, mv, intradc, coeff_index) + coefficient blocks -> bytes.
 
     The quantiser of each coded macroblock must be reachable from the previous one by a DQUANT of
     {-2,-1,0,1,2}; Q types are chosen automatically.  overflow_blocks: set of (mb, blk) whose coded block gets an
     extra event with run 63, i.e. the `kill` path."""
     bw = BitWriter()
-    bw.put(1, 17)                                     # start code
-    bw.put(version, 5)
-    bw.put(temporal_reference, 8)
-    if (width, height) in FORMATS:
-        bw.put(FORMATS[(width, height)], 3)
-    elif width < 256 and height < 256:
-        bw.put(0, 3); bw.put(width, 8); bw.put(height, 8)
+    umv = False
+    if standard is not None:
+        std = dict(standard)
+        umv = std.pop("umv", False)
+        write_standard_header(bw, width, height, picture_type, pquant, temporal_reference, **std)
     else:
-        bw.put(1, 3); bw.put(width, 16); bw.put(height, 16)
-    bw.put(picture_type, 2)
-    bw.put(deblock_flag, 1)
-    bw.put(pquant, 5)
-    bw.put(0, 1)                                      # PEI
+        bw.put(1, 17)                                     # start code
+        bw.put(version, 5)
+        bw.put(temporal_reference, 8)
+        if (width, height) in FORMATS:
+            bw.put(FORMATS[(width, height)], 3)
+        elif width < 256 and height < 256:
+            bw.put(0, 3); bw.put(width, 8); bw.put(height, 8)
+        else:
+            bw.put(1, 3); bw.put(width, 16); bw.put(height, 16)
+        bw.put(picture_type, 2)
+        bw.put(deblock_flag, 1)
+        bw.put(pquant, 5)
+        bw.put(0, 1)                                      # PEI
     mbw = (width + 15) // 16
     quant = pquant
     pv = []
@@ -177,8 +266,12 @@ def encode_picture(width, height, picture_type, pquant, mbs, coeffs, temporal_re
             cur = [list(x) for x in cur]
             for k in range(4 if four else 1):
                 p = predict(pv, cur, mbw, k)
-                bw.code(MVD[mvd_for(int(mv[k][0]), p[0])])
-                bw.code(MVD[mvd_for(int(mv[k][1]), p[1])])
+                if umv:                               # Annex D: the difference itself, any size
+                    write_umv(bw, int(mv[k][0]) - p[0])
+                    write_umv(bw, int(mv[k][1]) - p[1])
+                else:
+                    bw.code(MVD[mvd_for(int(mv[k][0]), p[0])])
+                    bw.code(MVD[mvd_for(int(mv[k][1]), p[1])])
                 cur[k] = [int(mv[k][0]), int(mv[k][1])]
             if not four:
                 cur = [cur[0]] * 4
@@ -188,6 +281,6 @@ def encode_picture(width, height, picture_type, pquant, mbs, coeffs, temporal_re
             coded = (cbp >> b) & 1
             c = coeffs[ci] if coded else None
             extra = [(63, 1)] if (i, b) in overflow_blocks else ()
-            write_block(bw, c, intra, m["intradc"][b], coded, extra)
+            write_block(bw, c, intra, m["intradc"][b], coded, extra, standard=standard is not None)
             ci += coded
     return bw.tobytes()

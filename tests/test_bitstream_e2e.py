@@ -109,7 +109,8 @@ def test_parser_error_classes():
     # ... and somewhere in the stream there is a cut that lands inside a block
     assert any(pl.parse_picture(data[:c])[0] == pl.EOF_ERR for c in range(cut, cut + 12))
     assert pl.parse_picture(bytes([0x12, 0x34, 0x56, 0x78, 0x9A]))[0] == -2          # no start code: MiddleOfBitstream
-    assert pl.parse_picture(data, options=0)[0] == -17                               # standard H.263 headers: row f-4
+    # read as standard H.263 the Sorenson version field is a GOB number != 0: not a picture (picture.rs:660-662)
+    assert pl.parse_picture(data, options=0)[0] == -2
     bad = bytearray(enc.encode_picture(w, h, 2, 5, mbs[:1], coeffs))                 # disposable P: macroblock.rs:461-465
     assert pl.parse_picture(bytes(bad))[0] == -17
     # reserved source format 7 has no dimensions: PictureFormatInvalid (state.rs:169-171)
@@ -182,10 +183,10 @@ def test_decode_next_picture_errors_leave_state_unchanged():
     rc, want = orc.decode_picture(w, h, pm2[:40], pc, before)
     for g, e in zip(st.get_last_picture().as_yuv(), want):
         assert (g == e).all()
-    # standard H.263 streams are not parsed yet (row f-4)
+    # a Sorenson picture handed to a standard H.263 state: its version field reads as a GOB number (picture.rs:660-662)
     st2 = h263mi.H263State(0)
     with pytest.raises(h263mi.H263Error) as e:
         st2.decode_next_picture(i_data)
-    assert e.value.code == h263mi.ERR_UNIMPLEMENTED_DECODING
+    assert e.value.code == h263mi.ERR_MIDDLE_OF_BITSTREAM
     st.close()
     st2.close()

@@ -134,13 +134,15 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     // cache lines the 4-pixel tile offset straddles -- are thus in different workgroups, start at slightly
     // different times, and the second one finds the shared lines in L2 (4 lock-stepped waves of one
     // workgroup missing on the same line at the same moment fetched it twice: +50 % FETCH_SIZE).
-    const uint32_t groups_y = (a.tiles_y + POST_WAVES - 1) / POST_WAVES;
-    const uint32_t wpp = a.tiles_x * groups_y, wgs = wpp * a.n_pictures;
-    const uint32_t chunk = (wgs + 7) / 8, xcd = blockIdx.x & 7;
-    const uint32_t t = blockIdx.x >> 3, wg = xcd * chunk + t;
-    if (t >= chunk || wg >= wgs) return;
+    const uint32_t groups_y = (a.tiles_y + POST_GROUP - 1) / POST_GROUP;
+    const uint32_t wpp = a.tiles_x * groups_y, units = wpp * a.n_pictures * (POST_GROUP / POST_WAVES);
+    const uint32_t chunk = (units + 7) / 8, xcd = blockIdx.x & 7;
+    const uint32_t t = blockIdx.x >> 3, unit = xcd * chunk + t;
+    if (t >= chunk || unit >= units) return;
+    const uint32_t wg = unit / (POST_GROUP / POST_WAVES);
+    const int gw = (int)(unit % (POST_GROUP / POST_WAVES)) * POST_WAVES + wave;       // tile of the group, 0..3
     const int pic = (int)(wg / wpp), rem = (int)(wg % wpp);
-    const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_WAVES + wave;
+    const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_GROUP + gw;
     if (ty >= (int)a.tiles_y) return;
     const int sy0 = ty * POST_STRIPS;
     // no workgroup barrier anywhere: the wave owns its strips from load to store.  All loads of the
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 
 hipError_t launch_post(const PostArgs &args, hipStream_t stream)
 {
-    const uint32_t groups_y = (args.tiles_y + POST_WAVES - 1) / POST_WAVES;
-    const uint32_t wgs = args.tiles_x * groups_y * args.n_pictures, chunk = (wgs + 7) / 8;
+    const uint32_t groups_y = (args.tiles_y + POST_GROUP - 1) / POST_GROUP;
+    const uint32_t units = args.tiles_x * groups_y * args.n_pictures * (POST_GROUP / POST_WAVES), chunk = (units + 7) / 8;
     hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, args);
     return hipGetLastError();
 }

@@ -24,12 +24,16 @@
 
 namespace h263mi {
 
-constexpr int POST_THREADS = 256;
+#ifndef H263MI_POST_WAVES
+#define H263MI_POST_WAVES 1       // measured: 1 -> 0.157 ms, 2 -> 0.162 ms, 4 -> 0.162 ms per launch (64 x 1080p)
+#endif
+constexpr int POST_WAVES = H263MI_POST_WAVES;       // waves per workgroup (independent: 1, 2 or 4)
+constexpr int POST_THREADS = POST_WAVES * 64;
+constexpr int POST_GROUP = 4;                       // vertically adjacent tiles that follow each other in the work list
 constexpr int POST_TW = 128, POST_TH = 32;          // luma tile of a workgroup = 4 strips of 8 rows
 constexpr int POST_SH = 8;                          // luma rows per strip (one wave)
 constexpr int POST_CW = 64, POST_CSH = 4;           // chroma strip
 constexpr int POST_OX = POST_TW - 4;                // strip column sx starts at sx*128 - 124
-constexpr int POST_WAVES = POST_THREADS / 64;
 constexpr int POST_STRIPS = 4;                      // strips (vertical neighbours) per wave = one 128x32 tile
 
 struct PostStrip {

@@ -90,15 +90,15 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
     PostStrip *s = (PostStrip *)aligned_alloc(16, (sizeof(PostStrip) + 15) / 16 * 16);
     // same work decomposition as kernels.hip::k_post: XCD-ordered workgroups of 4 waves, one tile
     // (4 strips) per wave, all loads of the tile first
-    const uint32_t groups_y = (a.tiles_y + POST_WAVES - 1) / POST_WAVES;
+    const uint32_t groups_y = (a.tiles_y + POST_GROUP - 1) / POST_GROUP;
     const uint32_t wpp = a.tiles_x * groups_y, wgs = wpp * n_pictures, chunk = (wgs + 7) / 8;
     static PostFetch pf[POST_STRIPS][64];
     for (uint32_t b = 0; b < chunk * 8; b++) {
         const uint32_t xcd = b & 7, t = b >> 3, wg = xcd * chunk + t;
         if (t >= chunk || wg >= wgs) continue;
-        for (int wave = 0; wave < POST_WAVES; wave++) {
+        for (int wave = 0; wave < POST_GROUP; wave++) {
             const int pic = wg / wpp, rem = wg % wpp;
-            const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_WAVES + wave;
+            const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_GROUP + wave;
             if (ty >= (int)a.tiles_y) continue;
             const int sy0 = ty * POST_STRIPS;
             for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[0][l], l, sx, sy0, pic);

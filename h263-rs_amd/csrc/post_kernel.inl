@@ -47,31 +47,90 @@ H263_HD uint32_t post_strips_y(uint32_t h) { return (h + 4 + POST_SH - 1) / POST
 // (floor), its scalar tails with `/` (truncation toward zero).  Both are one shift once a bias is added to
 // negative numerators: trunc(x / 2^k) = (x + ((x >> 31) & (2^k - 1))) >> k.  `tm` is 0 for the floor semantics
 // and all ones for truncation, so the bias vanishes where the reference shifts.
-H263_HD int div_pow2(int x, int k, int tm) { return (x + ((x >> 31) & ((1 << k) - 1) & tm)) >> k; }
+//
+// The rest is arranged for the instruction prices of gfx950 (profiles/r01_valu_rate.txt: add / sub / and / xor /
+// shifts right are half the price of min / max / compare / select):
+//   up_down_ramp (deblock.rs:13-15)  max(0, |d| - max(0, 2(|d| - S))) = median(0, |d|, 2S - |d|)
+//   |d1 / 2|: d1 = +-mag, so it is mag >> 1, or (mag + 1) >> 1 for a negative d1 under floor division
+//   clipd1 (deblock.rs:19-21) and the two saturating outputs are medians as well
+H263_HD int median3_i32(int a, int b, int c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+#endif
+}
+
+// (x >> 31) & m as two plain instructions (the compiler otherwise turns it into compare + select)
+H263_HD int sign_and(int x, int m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int s;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(s) : "v"(x));
+    return s & m;
+#else
+    return (x >> 31) & m;
+#endif
+}
+
+H263_HD void deblock_quartet_tm(int &A, int &B, int &C, int &D, int strength, int tm)
+{
+    const int ad_ = A - D;
+    const int x = ad_ + 4 * (C - B);
+    const int d = (x + sign_and(x, 7 & tm)) >> 3;
+    const int sd = d >> 31;                                   // 0 or -1
+    const int nd = -d;
+    const int ad = d > nd ? d : nd;                           // |d|
+    const int mag = median3_i32(ad, 0, 2 * strength - ad);    // |d1|
+    const int d1 = (mag ^ sd) - sd;
+    const int lim = (mag + (sd & ~tm & 1)) >> 1;              // |d1 / 2| in the division of this position
+    const int q = (ad_ + sign_and(ad_, 3 & tm)) >> 2;
+    const int d2 = median3_i32(q, -lim, lim);
+    A = A - d2;                                               // `as u8`: wraps, no clamp -- the caller keeps the low byte only
+    B = median3_i32(B + d1, 0, 255);
+    C = median3_i32(C - d1, 0, 255);
+    D = D + d2;                                               // likewise
+}
 
 H263_HD void deblock_quartet(int &A, int &B, int &C, int &D, int strength, bool floor_sem)
 {
-    const int tm = floor_sem ? 0 : -1;
-    const int ad_ = A - D;
-    const int d = div_pow2(ad_ + 4 * (C - B), 3, tm);
-    const int sd = d >> 31;                                   // 0 or -1
-    const int ad = (d ^ sd) - sd;                             // |d|
-    // up_down_ramp (deblock.rs:13-15): signum(d) * max(0, |d| - max(0, 2*(|d| - strength)))
-    int t = 2 * (ad - strength);
-    t = t < 0 ? 0 : t;
-    int mag = ad - t;
-    mag = mag < 0 ? 0 : mag;
-    const int d1 = (mag ^ sd) - sd;
-    const int half = div_pow2(d1, 1, tm);
-    const int sh = half >> 31;
-    const int lim = (half ^ sh) - sh;
-    const int d2 = clampi(div_pow2(ad_, 2, tm), -lim, lim);   // clipd1 (deblock.rs:19-21)
-    A = (A - d2) & 0xff;                                      // `as u8`: wraps, no clamp
-    B = clampi(B + d1, 0, 255);
-    C = clampi(C - d1, 0, 255);
-    D = (D + d2) & 0xff;
+    deblock_quartet_tm(A, B, C, D, strength, floor_sem ? 0 : -1);
 }
 
+// tm for position `pos` against the end of the reference's SIMD region: 0 (floor) for pos < simd_end, else -1
+H263_HD int trunc_mask(int pos, int simd_end) { return (simd_end - 1 - pos) >> 31; }
+
+// byte shuffles of the filtered samples (v_perm_b32 picks byte 0 of each operand: no masks, no shifts)
+// bytes 0,1 of `keep_lo` below bytes 0,1 of `put_hi`
+H263_DEV uint32_t splice_lo16_hi16(uint32_t keep_lo, uint32_t put_hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(put_hi, keep_lo, 0x05040100u);
+#else
+    return (keep_lo & 0xffffu) | (put_hi << 16);
+#endif
+}
+// bytes 0,1 of `put_lo` below bytes 2,3 of `keep_hi`
+H263_DEV uint32_t splice_put16_keep16(uint32_t put_lo, uint32_t keep_hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(keep_hi, put_lo, 0x07060100u);
+#else
+    return (put_lo & 0xffffu) | (keep_hi & 0xffff0000u);
+#endif
+}
+H263_DEV uint32_t pack2_u8(int lo, int hi)                     // (lo & 0xff) | (hi & 0xff) << 8
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x0c0c0400u);
+#else
+    return ((uint32_t)lo & 0xffu) | (((uint32_t)hi & 0xffu) << 8);
+#endif
+}
 // ---- phase 0: strip -> registers -> LDS -----------------------------------------------------
 struct PostFetch {
     uint32_t y[4];
@@ -132,21 +191,19 @@ H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch
 // filter 2 neighbouring columns of the horizontal edge whose A row is `row_a`
 H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, int gx0, int floor_cols, int w)
 {
-    uint32_t r[4], o[4] = {0, 0, 0, 0};
+    uint32_t r[4];
+    int v[2][4];
 #pragma unroll
     for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        int A = (r[0] >> (8 * k)) & 0xff, B = (r[1] >> (8 * k)) & 0xff, C = (r[2] >> (8 * k)) & 0xff, D = (r[3] >> (8 * k)) & 0xff;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[k][q] = (int)((r[q] >> (8 * k)) & 0xff);
         const int gx = gx0 + k;
-        if (gx >= 0 && gx < w) deblock_quartet(A, B, C, D, strength, gx < floor_cols);
-        o[0] |= (uint32_t)A << (8 * k);
-        o[1] |= (uint32_t)B << (8 * k);
-        o[2] |= (uint32_t)C << (8 * k);
-        o[3] |= (uint32_t)D << (8 * k);
+        if (gx >= 0 && gx < w) deblock_quartet_tm(v[k][0], v[k][1], v[k][2], v[k][3], strength, trunc_mask(gx, floor_cols));
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col) = (uint16_t)o[q];
+    for (int q = 0; q < 4; q++) *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col) = (uint16_t)pack2_u8(v[0][q], v[1][q]);
 }
 
 // ---- phase 1: the horizontal block edge of the strip (deblock_horiz, deblock.rs:136-181) ------
@@ -184,10 +241,10 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
         if (gy >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
             uint64_t v = *reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]);
             int A = (v >> 16) & 0xff, B = (v >> 24) & 0xff, C = (v >> 32) & 0xff, D = (v >> 40) & 0xff;
-            deblock_quartet(A, B, C, D, strength, gy < (h / 8) * 8);
-            v = (v & 0xffff00000000ffffull) | ((uint64_t)A << 16) | ((uint64_t)B << 24) | ((uint64_t)C << 32) |
-                ((uint64_t)D << 40);
-            *reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]) = v;
+            deblock_quartet_tm(A, B, C, D, strength, trunc_mask(gy, (h / 8) * 8));
+            const uint32_t lo = splice_lo16_hi16((uint32_t)v, pack2_u8(A, B));
+            const uint32_t hi = splice_put16_keep16(pack2_u8(C, D), (uint32_t)(v >> 32));
+            *reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]) = (uint64_t)lo | ((uint64_t)hi << 32);
         }
     }
     if (a.luma_only) return;
@@ -199,8 +256,8 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
         if (gy >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
             uint32_t v = *reinterpret_cast<uint32_t *>(&s.c[plane][row * POST_CW + 8 * j + 4]);
             int A = v & 0xff, B = (v >> 8) & 0xff, C = (v >> 16) & 0xff, D = (v >> 24) & 0xff;
-            deblock_quartet(A, B, C, D, strength, gy < (h / 8) * 8);
-            v = (uint32_t)A | ((uint32_t)B << 8) | ((uint32_t)C << 16) | ((uint32_t)D << 24);
+            deblock_quartet_tm(A, B, C, D, strength, trunc_mask(gy, (h / 8) * 8));
+            v = splice_lo16_hi16(pack2_u8(A, B), pack2_u8(C, D));
             *reinterpret_cast<uint32_t *>(&s.c[plane][row * POST_CW + 8 * j + 4]) = v;
         }
     }

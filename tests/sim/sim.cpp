@@ -141,4 +141,29 @@ int sim_synth_picture(int kind, uint32_t w, uint32_t h, uint32_t stream_id, uint
     *n_blocks = used;
     return 0;
 }
+
+// Every (A - D, C - B) pair, each at the low and the high end of the byte range, strengths 1..12, against the
+// reference-shaped quartet `ref` (the oracle's process_scalar / process_simd_lane, passed in by the test).
+// Returns the number of mismatches; first[] = A,B,C,D,strength of the first one.
+int sim_quartet_sweep(void (*ref)(uint8_t *, uint8_t *, uint8_t *, uint8_t *, uint8_t), int floor_sem, int *first)
+{
+    int bad = 0;
+    for (int strength = 1; strength <= 12; strength++)
+        for (int x = -255; x <= 255; x++)
+            for (int px = 0; px < 2; px++)
+                for (int y = -255; y <= 255; y++)
+                    for (int py = 0; py < 2; py++) {
+                        const int a0 = (x > 0 ? x : 0) + (px ? 255 - (x > 0 ? x : -x) : 0), d0 = a0 - x;
+                        const int c0 = (y > 0 ? y : 0) + (py ? 255 - (y > 0 ? y : -y) : 0), b0 = c0 - y;
+                        int A = a0, B = b0, C = c0, D = d0;
+                        deblock_quartet(A, B, C, D, strength, floor_sem != 0);
+                        uint8_t ra = (uint8_t)a0, rb = (uint8_t)b0, rc = (uint8_t)c0, rd = (uint8_t)d0;
+                        ref(&ra, &rb, &rc, &rd, (uint8_t)strength);
+                        if ((A & 0xff) != ra || B != rb || C != rc || (D & 0xff) != rd) {
+                            if (!bad) { first[0] = a0; first[1] = b0; first[2] = c0; first[3] = d0; first[4] = strength; }
+                            bad++;
+                        }
+                    }
+    return bad;
+}
 }

@@ -165,3 +165,18 @@ def test_asan_build_runs_clean():
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "asan-ok" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("floor_sem", [0, 1])
+def test_quartet_arithmetic_matches_the_oracle_for_every_difference(floor_sem):
+    """deblock_quartet (medians, biased shifts) vs the reference-shaped process functions of the oracle: every
+    (A - D, C - B), at both ends of the byte range, strengths 1..12 -- 12.5 M quartets per division semantics."""
+    import ctypes as C
+    from oracle import oracle as orc_mod
+    L = simlib.lib()
+    ref = getattr(orc_mod.lib(), "orc_deblock_process_simd_lane" if floor_sem else "orc_deblock_process_scalar")
+    first = (C.c_int * 5)()
+    L.sim_quartet_sweep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.sim_quartet_sweep.restype = C.c_int
+    bad = L.sim_quartet_sweep(C.cast(ref, C.c_void_p), floor_sem, first)
+    assert bad == 0, (bad, list(first))

@@ -19,22 +19,49 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#if defined(H263MI_PROFILE_PHASES)
+// diagnosis build: wall-clock cycles (s_memtime) a wave spends in each phase of k_recon, summed over waves
+__device__ unsigned long long g_phase_cycles[8];
+#define PHASE_MARK(i)                                                                  \
+    do {                                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        if (lane == 0) atomicAdd(&g_phase_cycles[i], now_ - t_prev_);                  \
+        t_prev_ = now_;                                                                \
+    } while (0)
+extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(g_phase_cycles)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
 // workgroup, tiles taken in XCD-aware order (see k_post below).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
+// 5.8 KB of LDS per wave caps the residency at 7 waves per SIMD, i.e. 72 VGPRs: say so, or the compiler aims for 8
+// waves (64 VGPRs) and spills the rare border path to scratch
+__global__ __launch_bounds__(RECON_THREADS) __attribute__((amdgpu_waves_per_eu(1, 7))) void k_recon(ReconArgs a)
 {
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
     ReconWave &s = waves[wave];
-    // work list = (picture, tile, wave of the tile); a workgroup takes RECON_WAVES consecutive entries
-    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures * (TILE_WAVES / RECON_WAVES);
+    // work list = (picture, tile, macroblock row of the tile[, half]); a workgroup takes RECON_WAVES consecutive
+    // entries.  With RECON_HALVES == 2 a wave does both halves of its macroblock row one after the other: the
+    // records are fetched (and waited for) once, and the second half finds its reference rows in L1.
+    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES;
+    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures * (kUnitsPerTile / RECON_WAVES);
     const uint32_t chunk = (total + 7) / 8, xcd = blockIdx.x & 7;
     const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
     if (t >= chunk || g >= total) return;
-    const uint32_t tile_g = g / (TILE_WAVES / RECON_WAVES);
-    const int tw = (int)(g % (TILE_WAVES / RECON_WAVES)) * RECON_WAVES + wave;       // wave of the tile, 0..3
+    const uint32_t tile_g = g / (kUnitsPerTile / RECON_WAVES);
+    const int tw = ((int)(g % (kUnitsPerTile / RECON_WAVES)) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
     const int tile = (int)(tile_g % tpp);
     WavePos p;
     p.pic = (int)(tile_g / tpp);
@@ -44,32 +71,48 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     if (p.mby >= (int)a.L.mbh) return;
     p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
 
+#if defined(H263MI_PROFILE_PHASES)
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     recon_phase_load(a, s, lane, p);
-    recon_phase_mark(a, s, lane, p);
-    recon_phase_compact(a, s, lane);
-    WaveFetch f;
-    recon_phase_fetch(a, s, f, lane, p);          // every global load of the wave is in flight from here
-    const int n_active = recon_n_active(s);
+    PHASE_MARK(0);                                  // records requested and in LDS
     // `ln`: the lane index behind an opaque asm, re-derived per phase so that lane-only expressions are
     // recomputed where they are used instead of being kept in registers across the whole kernel
     int ln = lane;
 #pragma unroll 1
-    for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
+    for (int h = 0; h < RECON_HALVES; h++, p.half++) {
         asm volatile("" : "+v"(ln));
-        RowIn ri;
-        recon_phase_idct_load(a, s, f, ln, p, round, ri);
-        // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
-        const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
-                            (__ballot(ri.w[3] != 0) ? 8u : 0u);
-        const uint64_t rb = __ballot(recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm)));      // bit slot*8 + row
-        uint32_t rows_mask = (uint32_t)rb | (uint32_t)(rb >> 32);
-        rows_mask |= rows_mask >> 16;
-        rows_mask |= rows_mask >> 8;
+        recon_phase_mark(a, s, ln, p);
+        recon_phase_compact(a, s, ln);
+        PHASE_MARK(1);
+        WaveFetch f;
+        recon_phase_fetch(a, s, f, ln, p);          // every global load of this half is in flight from here
+        const int n_active = recon_n_active(s);
+        PHASE_MARK(2);
+#pragma unroll 1
+        for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
+            asm volatile("" : "+v"(ln));
+            RowIn ri;
+            recon_phase_idct_load(a, s, f, ln, p, round, ri);
+            // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
+            const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
+                                (__ballot(ri.w[3] != 0) ? 8u : 0u);
+            const uint64_t rb = __ballot(recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm)));      // bit slot*8 + row
+            uint32_t rows_mask = (uint32_t)rb | (uint32_t)(rb >> 32);
+            rows_mask |= rows_mask >> 16;
+            rows_mask |= rows_mask >> 8;
+            asm volatile("" : "+v"(ln));
+            recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu));
+        }
+        PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
+#if defined(H263MI_PROFILE_PHASES)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE_MARK(4);                              // reference rows have arrived
+#endif
         asm volatile("" : "+v"(ln));
-        recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu));
+        recon_phase_output(a, s, f, ln, p);
+        PHASE_MARK(5);
     }
-    asm volatile("" : "+v"(ln));
-    recon_phase_output(a, s, f, ln, p);
 }
 
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
@@ -80,7 +123,7 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
     }();
     ReconArgs a = args;
     a.debug_flags |= env_debug;
-    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures * (TILE_WAVES / RECON_WAVES);
+    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures * (TILE_WAVES / RECON_HALVES / RECON_WAVES);
     const uint32_t chunk = (total + 7) / 8;
     hipLaunchKernelGGL(k_recon, dim3(chunk * 8), dim3(RECON_THREADS), 0, stream, a);
     return hipGetLastError();

@@ -331,6 +331,8 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
                 }
                 uint8_t *dst = rgba + ((size_t)gy * w + gx) * 4;
                 if (gx + 4 <= w && (w & 3) == 0) {
+                    // (non-temporal stores here were measured: k_recon gains 5 % from finding its reference planes
+                    // in the infinity cache, k_post loses 10-25 %)
                     *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
                 } else {
                     for (int k = 0; k < 4 && gx + k < w; k++) memcpy(dst + 4 * k, &px[k], 4);

@@ -45,9 +45,7 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 // k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
 // workgroup, tiles taken in XCD-aware order (see k_post below).
 // ---------------------------------------------------------------------------------------
-// 5.8 KB of LDS per wave caps the residency at 7 waves per SIMD, i.e. 72 VGPRs: say so, or the compiler aims for 8
-// waves (64 VGPRs) and spills the rare border path to scratch
-__global__ __launch_bounds__(RECON_THREADS) __attribute__((amdgpu_waves_per_eu(1, 7))) void k_recon(ReconArgs a)
+__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 {
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar

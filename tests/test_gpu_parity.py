@@ -135,6 +135,22 @@ def test_state_intra_then_inter_chain(w, h):
     st.close()
 
 
+@pytest.mark.parametrize("w,h,mv_range", [(176, 144, 600), (100, 60, 200), (16, 16, 1100), (320, 240, 1100), (1920, 1080, 300)])
+def test_state_far_vectors_and_large_levels(w, h, mv_range):
+    """vectors far outside the picture (every tap clamps to an edge pixel) and 11-bit levels at quantiser 31"""
+    st = h263mi.H263State()
+    mbs, coeffs = recgen.intra_picture(w, h, seed=3)
+    st.submit_picture(w, h, mbs, coeffs, h263mi.PICTURE_I)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, None)
+    mbs, coeffs = recgen.inter_picture(w, h, seed=mv_range + w, mv_range=mv_range, p_4v=0.4, p_intra=0.1, p_coded=0.5,
+                                       quant=31, max_level=1023, sparse_low=False)
+    st.submit_picture(w, h, mbs, coeffs, h263mi.PICTURE_P)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, want)
+    assert rc == 0
+    assert_planes_equal(st.get_last_picture().as_yuv(), want, "P")
+    st.close()
+
+
 def test_state_errors_leave_state_unchanged():
     w, h = 64, 48
     st = h263mi.H263State()

@@ -38,6 +38,20 @@ def test_recon_inter(w, h):
         assert (g == e).all(), (name, np.flatnonzero(g != e)[:10])
 
 
+@pytest.mark.parametrize("w,h,mv_range", [(176, 144, 600), (100, 60, 200), (16, 16, 1100), (48, 32, 64), (320, 240, 1100)])
+def test_recon_far_vectors_and_large_levels(w, h, mv_range):
+    """vectors far outside the picture (Annex D ranges and beyond: every tap clamps to an edge pixel), 11-bit
+    Sorenson levels at quantiser 31"""
+    ref = recgen.random_planes(w, h, 5)
+    mbs, coeffs = recgen.inter_picture(w, h, seed=mv_range + w, mv_range=mv_range, p_4v=0.4, p_intra=0.1, p_coded=0.5,
+                                       quant=31, max_level=1023, sparse_low=False)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+    st, got = simlib.recon(w, h, mbs, coeffs, ref)
+    assert rc == 0 and st == 0
+    for g, e, name in zip(got, want, "Y Cb Cr".split()):
+        assert (g == e).all(), (name, np.flatnonzero(g != e)[:10])
+
+
 def test_recon_short_picture_is_padded_and_errors_without_reference():
     w, h = 64, 48
     ref = recgen.random_planes(w, h, 3)

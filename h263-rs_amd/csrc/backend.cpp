@@ -394,7 +394,7 @@ uint32_t h263mi_batch_mbs_per_picture(const h263mi_batch *b) { return b ? b->L.m
 int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs, const int16_t *d_coeffs,
                         const uint64_t *d_coeff_base)
 {
-    if (!b || !d_mbs || picture_type > H263MI_PICTURE_DISPOSABLE_P) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!b || !d_mbs || picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     return b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base);
 }
@@ -506,7 +506,7 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, cons
 {
     if (!s || !desc || (!mbs && n_mbs) || (!coeffs && n_coeff_blocks)) return H263MI_ERR_INVALID_ARGUMENT;
     if (!desc->width || !desc->height) return H263MI_ERR_PICTURE_FORMAT_INVALID;
-    if (desc->picture_type > H263MI_PICTURE_DISPOSABLE_P) return H263MI_ERR_INVALID_ARGUMENT;
+    if (desc->picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;
     const FrameLayout L = make_layout(desc->width, desc->height);
     const size_t total = (size_t)L.mbw * L.mbh;
     if (n_mbs > total) return H263MI_ERR_INVALID_ARGUMENT;

@@ -323,6 +323,19 @@ def test_standard_stream_decodes_like_the_oracle(w, h, std):
         assert pic.temporal_reference == f
         for g, e in zip(pic.as_yuv(), ref):
             assert (g == e).all()
+    # a B picture made of COD = 1 macroblocks only never reaches the unimplemented MCBPC branch: it decodes as a copy of
+    # the last picture and, not being "disposable", becomes the reference like any other (state.rs:464-480)
+    bstd = dict(std, plus=True, mpp_type=3)       # OPPTYPE restates the same SourceFormat: no "format change"
+    hdr = enc.BitWriter()
+    enc.write_standard_header(hdr, w, h, 1, 8, 9, **bstd)
+    hdr_bits = sum(len(x) for x in hdr.bits)
+    skip = np.zeros(8 + (-hdr_bits) % 8, pm.dtype)  # end on a byte boundary: padding bits would be read as a coded macroblock
+    skip["quant"] = 8
+    st.decode_next_picture(enc.encode_picture(w, h, 1, 8, skip, pc[:0], temporal_reference=9, standard=bstd))
+    pic = st.get_last_picture()
+    assert pic.picture_type == h263mi.PICTURE_B and pic.temporal_reference == 9
+    for g, e2 in zip(pic.as_yuv(), ref):
+        assert (g == e2).all()
     # a format change is the reference's RPRP stub; the state keeps its picture
     with pytest.raises(h263mi.H263Error) as e:
         st.decode_next_picture(enc.encode_picture(128, 96, 1, 8, pm[:1], pc, standard={}))

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <new>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "../host/bitstream.hpp"
@@ -84,6 +86,16 @@ struct h263mi_batch {
     uint32_t *d_status = nullptr;
     uint32_t *h_status = nullptr;              // pinned
     uint64_t coeff_pool_blocks = 0;            // 0 = unchecked
+    // host-record staging for h263mi_batch_submit_host: two slots (pinned host + device) used alternately, so
+    // that packing picture i+1 overlaps the copy and the kernel of picture i
+    struct HostStaging {
+        MbRecord *h_mbs = nullptr, *d_mbs = nullptr;
+        int16_t *h_coeffs = nullptr, *d_coeffs = nullptr;
+        uint64_t *h_base = nullptr, *d_base = nullptr;
+        size_t cap_blocks = 0;
+        hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
+    } host_stg[2];
+    unsigned host_slot = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -130,6 +142,37 @@ struct h263mi_batch {
         if (d_status) (void)hipFree(d_status);
         if (h_status) (void)hipHostFree(h_status);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (HostStaging &g2 : host_stg) {
+            if (g2.h_mbs) (void)hipHostFree(g2.h_mbs);
+            if (g2.d_mbs) (void)hipFree(g2.d_mbs);
+            if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
+            if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
+            if (g2.h_base) (void)hipHostFree(g2.h_base);
+            if (g2.d_base) (void)hipFree(g2.d_base);
+            if (g2.done) (void)hipEventDestroy(g2.done);
+        }
+    }
+
+    int ensure_host_staging(HostStaging &g2, size_t n_blocks)
+    {
+        const size_t total = (size_t)n * L.mbw * L.mbh;
+        if (!g2.h_mbs) {
+            HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
+            HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
+            HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
+        }
+        if (n_blocks > g2.cap_blocks) {
+            if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
+            if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
+            g2.h_coeffs = nullptr; g2.d_coeffs = nullptr; g2.cap_blocks = 0;
+            const size_t cap = n_blocks + n_blocks / 2 + 64;
+            HIP_TRY(hipHostMalloc((void **)&g2.h_coeffs, cap * 128, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&g2.d_coeffs, cap * 128));
+            g2.cap_blocks = cap;
+        }
+        return H263MI_OK;
     }
 
     hipStream_t stream_of(int kernel_id) const { return (kernel_id == 1 && overlap_post) ? post_stream : stream; }
@@ -397,6 +440,61 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
     if (!b || !d_mbs || picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     return b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base);
+}
+
+int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
+                             const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks)
+{
+    if (!b || !mbs || !n_mbs || !coeffs || !n_coeff_blocks || picture_type > H263MI_PICTURE_RESERVED)
+        return H263MI_ERR_INVALID_ARGUMENT;
+    const size_t per = (size_t)b->L.mbw * b->L.mbh;
+    size_t blocks = 0;
+    for (uint32_t i = 0; i < b->n; i++) {
+        if (n_mbs[i] > per || (n_mbs[i] && !mbs[i]) || (n_coeff_blocks[i] && !coeffs[i])) return H263MI_ERR_INVALID_ARGUMENT;
+        blocks += n_coeff_blocks[i];
+    }
+    DeviceGuard g(b->device);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];
+    RC_TRY(b->ensure_host_staging(g2, blocks ? blocks : 1));
+    HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
+
+    MbRecord pad;                                // state.rs:421-427: Inter, mv (0,0), nothing coded
+    memset(&pad, 0, sizeof pad);
+    pad.mb_type = H263MI_MB_INTER;
+    pad.quant = 1;
+    size_t at = 0;
+    for (uint32_t i = 0; i < b->n; i++) {        // coeff_index of stream i counts from its own first block
+        g2.h_base[i] = at;
+        at += n_coeff_blocks[i];
+    }
+    // packing is a host memcpy of every record byte: a few threads, or one core caps the rate below the PCIe link
+    auto pack = [&](uint32_t first, uint32_t last) {
+        for (uint32_t i = first; i < last; i++) {
+            MbRecord *dst = g2.h_mbs + (size_t)i * per;
+            if (n_mbs[i]) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
+            for (size_t k = n_mbs[i]; k < per; k++) dst[k] = pad;
+            if (n_coeff_blocks[i]) memcpy(g2.h_coeffs + g2.h_base[i] * 64, coeffs[i], (size_t)n_coeff_blocks[i] * 128);
+        }
+    };
+    const size_t bytes = (size_t)b->n * per * sizeof(MbRecord) + blocks * 128;
+    const uint32_t n_thr = bytes < (4u << 20) ? 1u : std::min<uint32_t>({8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
+    if (n_thr <= 1) {
+        pack(0, b->n);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < n_thr; t++)
+            pool.emplace_back(pack, (uint32_t)((uint64_t)b->n * t / n_thr), (uint32_t)((uint64_t)b->n * (t + 1) / n_thr));
+        for (std::thread &t : pool) t.join();
+    }
+    HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, (size_t)b->n * per * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
+    if (blocks) HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
+    b->coeff_pool_blocks = blocks;
+    RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base));
+    HIP_TRY(hipEventRecord(g2.done, b->stream));
+    b->host_slot++;
+    return H263MI_OK;
 }
 
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)

@@ -49,7 +49,7 @@ EXPORTS = [
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
-    "h263mi_batch_timing_begin", "h263mi_batch_timing_end",
+    "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_submit_host",
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
     "h263mi_synth_picture_host", "h263mi_synth_batch_device",
@@ -129,6 +129,7 @@ def lib():
         L.h263mi_batch_mbs_per_picture.argtypes = [vp]
         L.h263mi_batch_mbs_per_picture.restype = u32
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
+        L.h263mi_batch_submit_host.argtypes = [vp, u8, vp, vp, vp, vp]
         L.h263mi_batch_render_rgba.argtypes = [vp, u8, vp, vp]
         L.h263mi_batch_sync.argtypes = [vp]
         L.h263mi_batch_reset.argtypes = [vp]
@@ -362,6 +363,17 @@ class Batch:
 
     def submit(self, picture_type, d_mbs, d_coeffs, d_coeff_base=None):
         _check(lib().h263mi_batch_submit(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base), "batch_submit")
+
+    def submit_host(self, picture_type, mbs_list, coeffs_list):
+        """one picture per stream from host records: lists of MB_RECORD_DTYPE arrays and (n, 64) int16 arrays"""
+        n = len(mbs_list)
+        mbs = [np.ascontiguousarray(m, MB_RECORD_DTYPE) for m in mbs_list]
+        cos = [np.ascontiguousarray(c, np.int16).reshape(-1, 64) for c in coeffs_list]
+        pm = (C.c_void_p * n)(*[m.ctypes.data if m.size else None for m in mbs])
+        pc = (C.c_void_p * n)(*[c.ctypes.data if c.size else None for c in cos])
+        nm = (C.c_uint32 * n)(*[len(m) for m in mbs])
+        nc = (C.c_uint32 * n)(*[len(c) for c in cos])
+        _check(lib().h263mi_batch_submit_host(self._h, picture_type, pm, nm, pc, nc), "batch_submit_host")
 
     def render_rgba(self, strength, d_rgba, d_deblocked=None):
         _check(lib().h263mi_batch_render_rgba(self._h, strength, d_rgba, d_deblocked), "batch_render_rgba")

@@ -258,6 +258,18 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
  * (DEVICE, n_streams * w*h*4 bytes, stream-major); d_deblocked (DEVICE, may be NULL)
  * additionally receives the filtered planes, n_streams * (w*h + 2*cw*ch) bytes as
  * Y,Cb,Cr per stream, tightly packed. */
+/*
+ * The same from HOST records, one picture per stream: the batch counterpart of h263mi_submit_picture for a server
+ * whose parser threads fill one record array per stream.  mbs[s] / coeffs[s] hold stream s' macroblocks
+ * (n_mbs[s] <= mbs_per_picture; missing ones are padded as Inter / mv 0, state.rs:421-427) and coded blocks
+ * (coeff_index counts from the stream's own first block).  The arrays are packed into pinned staging -- two slots,
+ * used alternately, so packing picture i+1 overlaps the copy and the kernel of picture i -- copied with one
+ * asynchronous H2D per array and decoded by one k_recon launch.  The host arrays may be reused on return.
+ * Records are not validated here beyond the counts; errors surface at h263mi_batch_sync like for h263mi_batch_submit.
+ */
+int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type,
+                             const h263mi_mb_record *const *mbs, const uint32_t *n_mbs,
+                             const int16_t *const *coeffs, const uint32_t *n_coeff_blocks);
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_sync(h263mi_batch *b);
 int h263mi_batch_reset(h263mi_batch *b);

@@ -387,3 +387,36 @@ def test_batch_reports_inter_without_reference():
         b.sync()
     assert e.value.code == h263mi.ERR_UNCODED_IFRAME_BLOCKS
     b.close()
+
+
+def test_batch_submit_host_matches_the_oracle_per_stream():
+    """h263mi_batch_submit_host: per-stream host record arrays (one short, one without coded blocks), packed and
+    decoded in one launch; the second picture reuses the other staging slot, the third the first again."""
+    w, h, n = 176, 144, 4
+    b = h263mi.Batch(n, w, h)
+    refs = [None] * n
+    for f in range(4):
+        mbs, cos = [], []
+        for s in range(n):
+            if f == 0:
+                m, c = recgen.intra_picture(w, h, seed=10 * s + 1)
+            else:
+                m, c = recgen.inter_picture(w, h, seed=100 * f + s, mv_range=40, p_4v=0.3, p_intra=0.1, p_coded=0.4,
+                                            quant=7)
+                if s == 1:
+                    m = m[:37]                                   # short picture: the rest is padded (state.rs:421-427)
+                    c = c[:int(m["coeff_index"][-1]) + bin(int(m["cbp"][-1])).count("1")]
+                if s == 2:
+                    m = m.copy()
+                    m["cbp"] = 0                                 # nothing coded at all
+                    m["mb_type"] = np.where(np.isin(m["mb_type"], (3, 4)), 0, m["mb_type"])
+                    c = c[:0]
+            mbs.append(m)
+            cos.append(c)
+        b.submit_host(h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, mbs, cos)
+        b.sync()
+        for s in range(n):
+            rc, refs[s] = orc.decode_picture(w, h, mbs[s], cos[s], refs[s])
+            assert rc == 0
+            assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
+    b.close()

@@ -49,3 +49,39 @@ st.get_last_picture()
 dt = (time.perf_counter() - t0) / 32
 print("dense I pictures (%.2f MB of records each): %.3f ms/picture = %.0f pictures/s, H2D %.1f GB/s"
       % ((dense[0].nbytes + dense[1].nbytes) / 1e6, dt * 1e3, 1 / dt, (dense[0].nbytes + dense[1].nbytes) / 1e9 / dt))
+
+# ---- many streams: h263mi_batch_submit_host, 32 streams x (I + 7 P) from per-stream host record arrays -------------
+import ctypes as C   # noqa: E402
+
+n = 32
+b = h263mi.Batch(n, W, H)
+per_frame = []
+for f in range(8):
+    kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
+    recs = [h263mi.synth_picture_host(kind, W, H, s, f) for s in range(4)]          # 4 distinct streams, reused
+    mbs = [recs[s % 4][0] for s in range(n)]
+    cos = [recs[s % 4][1].reshape(-1, 64) for s in range(n)]
+    pm = (C.c_void_p * n)(*[m.ctypes.data for m in mbs])
+    pc = (C.c_void_p * n)(*[c.ctypes.data for c in cos])
+    nm = (C.c_uint32 * n)(*[len(m) for m in mbs])
+    nc = (C.c_uint32 * n)(*[len(c) for c in cos])
+    nbytes = sum(m.nbytes + c.nbytes for m, c in zip(mbs, cos))
+    per_frame.append((h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, pm, nm, pc, nc, nbytes, (mbs, cos)))
+L = h263mi.lib()
+
+
+def run_batch(steps):
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pt, pm, nm, pc, nc, _, _ = per_frame[i % 8]
+        rc = L.h263mi_batch_submit_host(b._h, pt, pm, nm, pc, nc)
+        assert rc == 0, rc
+    b.sync()
+    return (time.perf_counter() - t0) / steps
+
+
+run_batch(8)
+dt = run_batch(32)
+mb = np.mean([p[5] for p in per_frame]) / 1e6
+print("batch_submit_host, %d streams (%.1f MB of records per step): %.3f ms/step = %.0f pictures/s = %.1f MP/s, "
+      "pack + H2D %.1f GB/s" % (n, mb, dt * 1e3, n / dt, n * W * H / 1e6 / dt, mb / 1e3 / dt))

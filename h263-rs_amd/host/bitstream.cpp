@@ -2,6 +2,7 @@
 // and, separately, into the CPU-only parser test library (tests/parser).
 #include "bitstream.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace h263mi {
@@ -21,12 +22,17 @@ const uint8_t kZigzagRaster[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 2
 // ---------------------------------------------------------------------------------------------------
 uint32_t BitReader::peek_padded(uint32_t n) const
 {
-    // gather up to 40 bits around the cursor into a 64-bit window
-    uint64_t window = 0;
+    if (!n) return 0u;
     const size_t byte = pos_ >> 3, nbytes = nbits_ >> 3;
-    for (size_t k = 0; k < 5; k++) window = (window << 8) | (byte + k < nbytes ? p_[byte + k] : 0);
-    const uint32_t shift = 40 - (uint32_t)(pos_ & 7) - n;
-    return n ? (uint32_t)((window >> shift) & ((n == 32) ? 0xffffffffull : ((1ull << n) - 1))) : 0u;
+    uint64_t window;                      // the 8 bytes at the cursor, big endian, zero padded past the end
+    if (byte + 8 <= nbytes) {
+        memcpy(&window, p_ + byte, 8);    // one unaligned load + byte swap
+        window = __builtin_bswap64(window);
+    } else {
+        window = 0;
+        for (size_t k = 0; k < 8; k++) window = (window << 8) | (byte + k < nbytes ? p_[byte + k] : 0);
+    }
+    return (uint32_t)((window << (pos_ & 7)) >> (64 - n));      // n <= 32 and (pos_ & 7) + n <= 39 < 64
 }
 
 int BitReader::peek_bits(uint32_t n, uint32_t &out) const
@@ -114,6 +120,8 @@ VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0)
         if (l > max_len_) max_len_ = l;
     }
     lut_.assign((size_t)1 << max_len_, Slot{0, 0, 0, 0, 0});
+    for (size_t i = 0; i < n; i++)          // payloads are small by construction (types, runs <= 40, levels <= 12, vectors +-32)
+        if (codes[i].v0 < -128 || codes[i].v0 > 127 || codes[i].v1 < -128 || codes[i].v1 > 127 || codes[i].v2 < -128 || codes[i].v2 > 127) abort();
     // For every max_len_-bit pattern: the length at which a bit-by-bit walk of the code tree stops --
     // either on a code word, or on the shortest prefix that no code word starts with (the tree's
     // "invalid" leaves).
@@ -133,7 +141,7 @@ VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0)
                 }
             }
             if (is_code) {
-                lut_[pat] = Slot{(uint8_t)l, 1, codes[which].v0, codes[which].v1, codes[which].v2};
+                lut_[pat] = Slot{(uint8_t)l, 1, (int8_t)codes[which].v0, (int8_t)codes[which].v1, (int8_t)codes[which].v2};
                 break;
             }
             if (!extendable) {
@@ -178,7 +186,9 @@ H263MI_TABLE(mvd_table, kMvdCodes)
 int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, ParsedBlock &out)
 {
     const size_t checkpoint = r.position();          // with_transaction (block.rs:682)
-    out = ParsedBlock();
+    out.has_intradc = false;
+    out.intradc = 0;
+    out.n_tcoef = 0;
     int rc = H263MI_OK;
     do {
         if (intra) {
@@ -214,7 +224,7 @@ int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoe
                 is_short = false;
             } else {
                 uint32_t sign;
-                if ((rc = r.read_bits(1, sign)) != H263MI_OK) break;
+                if ((rc = r.read_bits(1, sign)) != H263MI_OK) break;     // (VlcTable::decode_with_bit could fold this in)
                 last = h.v0 != 0;
                 run = h.v1;
                 level = sign ? -(int)h.v2 : (int)h.v2;

@@ -66,7 +66,7 @@ public:
     int max_len() const { return max_len_; }
 
 private:
-    struct Slot { uint8_t len; uint8_t valid; int16_t v0, v1, v2; };
+    struct Slot { uint8_t len; uint8_t valid; int8_t v0, v1, v2; };     // 5 bytes: the 13-bit TCOEF table stays near L1 size
     std::vector<Slot> lut_;
     int max_len_;
 };
@@ -82,7 +82,7 @@ struct ParsedBlock {
     bool has_intradc = false;
     uint8_t intradc = 0;                   // raw FLC code
     int n_tcoef = 0;
-    struct { uint8_t is_short; uint8_t run; int16_t level; } tcoef[64 + 8];
+    struct { uint8_t is_short; uint8_t run; int16_t level; } tcoef[64 + 8];   // [0, n_tcoef) valid, the rest is not initialised
 };
 int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, ParsedBlock &out);
 

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: random picture sizes, record mixes, vectors, quantisers and filter
+strengths through the C ABI (state API) against the oracle.  Usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "h263-rs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+
+import h263mi
+import recgen
+from oracle import oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+n_pic = n_px = 0
+while time.time() < t_end:
+    w = int(rng.choice([rng.integers(1, 64), rng.integers(1, 420), 16 * rng.integers(1, 30), 176, 352]))
+    h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288]))
+    st = h263mi.H263State()
+    ref = None
+    for f in range(int(rng.integers(1, 5))):
+        s = int(rng.integers(0, 1 << 30))
+        if f == 0 or rng.random() < 0.15:
+            mbs, co = recgen.intra_picture(w, h, seed=s, max_level=int(rng.choice([3, 40, 127, 1023])))
+            pt = h263mi.PICTURE_I
+            want_ref = None
+        else:
+            mbs, co = recgen.inter_picture(w, h, seed=s, mv_range=int(rng.choice([2, 32, 70, 300])),
+                                           p_coded=float(rng.choice([0.05, 0.3, 0.9])), p_4v=float(rng.choice([0.0, 0.3, 1.0])),
+                                           p_intra=float(rng.choice([0.0, 0.2])), quant=int(rng.choice([0, 1, 10, 31])),
+                                           max_level=int(rng.choice([3, 60, 1023])), sparse_low=bool(rng.integers(0, 2)))
+            pt = h263mi.PICTURE_P
+            want_ref = ref
+        if want_ref is not None and rng.random() < 0.2 and len(mbs) > 2:     # a picture that ends early (padded as inter)
+            mbs = mbs[:int(rng.integers(1, len(mbs)))]
+        st.submit_picture(w, h, mbs, co, pt, temporal_reference=f)
+        rc, ref = orc.decode_picture(w, h, mbs, co, want_ref)
+        assert rc == 0
+        got = st.get_last_picture().as_yuv()
+        for g, e, name in zip(got, ref, "Y Cb Cr".split()):
+            if not (np.asarray(g) == e).all():
+                print("MISMATCH recon", w, h, f, s, name)
+                sys.exit(1)
+        strength = int(rng.integers(0, 13))
+        cw = (w + 1) // 2
+        planes = ref if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(ref, (w, cw, cw)))
+        if not (st.render_rgba(strength) == orc.yuv420_to_rgba(*planes, w)).all():
+            print("MISMATCH rgba", w, h, f, s, strength)
+            sys.exit(1)
+        n_pic += 1
+        n_px += w * h
+    st.close()
+print("fuzz ok: %d pictures, %.1f MP, seed %d, %.0f s" % (n_pic, n_px / 1e6, seed, budget))

@@ -1,11 +1,11 @@
 // dev_common.h -- types and helpers shared by the HIP kernels and their host launchers.
 //
-// Kernel bodies are written as per-phase inline functions taking explicit thread /
-// block indices (recon_kernel.inl, post_kernel.inl).  kernels.hip wraps them in
-// __global__ functions with __syncthreads() between phases.  tests/sim/ compiles the
-// same phase functions with g++ (ASan/UBSan) and runs the threads of a workgroup in a
-// loop, one phase at a time -- a logic checker for index math and edge handling, used
-// by the CPU test-suite only; it is not a product path.
+// Kernel bodies are written as per-phase inline functions taking an explicit lane index
+// and wave position (recon_kernel.inl, post_kernel.inl); kernels.hip calls them from the
+// __global__ functions, one wave per workgroup, no barriers.  tests/sim/ compiles the
+// same phase functions with g++ (ASan/UBSan) and runs the 64 lanes of a wave in a loop,
+// one phase at a time -- a logic checker for index math and edge handling, used by the
+// CPU test-suite only; it is not a product path.
 #pragma once
 
 #include <stdint.h>
@@ -22,9 +22,7 @@
 #define H263_HD inline
 // g++ build (tests/sim only): minimal stand-ins for the HIP vector types the phases use
 struct uint4 { uint32_t x, y, z, w; };
-struct float4 { float x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
-static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 #endif
 
 namespace h263mi {
@@ -91,7 +89,6 @@ struct ReconArgs {
     uint32_t mbs_per_picture;
     uint32_t has_ref;            // 0: inter macroblocks are an error
     uint32_t tiles_x, tiles_y;
-    uint32_t debug_flags;        // diagnosis only (env H263MI_DEBUG_RECON): 1 = no reference loads, 2 = no stores, 4 = no coefficient loads
 };
 
 // ---------------------------------------------------------------------------
@@ -106,7 +103,6 @@ struct PostArgs {
     uint32_t strength;           // 0 = no deblocking
     uint32_t tiles_x, tiles_y;
     uint32_t luma_only;          // standalone deblock() of a single plane
-    uint32_t debug_flags;        // diagnosis only (env H263MI_DEBUG_POST): 1 = no global loads, 2 = no stores
 };
 
 // ---------------------------------------------------------------------------
@@ -128,38 +124,6 @@ H263_HD int average_sum_of_mvs(int sum)
     int whole = (s >> 4) * 2;   // (s >> 4) << 1 in the reference; written without shifting a negative
     int frac = s & 15;
     return frac <= 2 ? whole : (frac >= 14 ? whole + 2 : whole + 1);
-}
-
-// rle.rs:130-133 dequantisation of one LEVEL (0 stays 0)
-H263_HD int dequant_level(int level, int quant)
-{
-    int a = level < 0 ? -level : level;
-    int m = quant * (2 * a + 1) - ((quant & 1) ? 0 : 1);
-    int v = level < 0 ? -m : m;
-    v = clampi(v, -2048, 2047);
-    return level == 0 ? 0 : v;
-}
-
-// per-byte (a + b + 1) >> 1 on 8 packed bytes: gather.rs:34-40 lerp, div_ceil(2)
-H263_HD uint64_t avg2_u8x8(uint64_t a, uint64_t b)
-{
-    return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f7f7f7f7full);
-}
-
-// per-byte (a + b + c + d + 2) >> 2 on 8 packed bytes: gather.rs:103-111
-H263_HD uint64_t avg4_u8x8(uint64_t a, uint64_t b, uint64_t c, uint64_t d)
-{
-    const uint64_t M = 0x00ff00ff00ff00ffull, R = 0x0002000200020002ull;
-    uint64_t e = (a & M) + (b & M) + (c & M) + (d & M) + R;
-    uint64_t o = ((a >> 8) & M) + ((b >> 8) & M) + ((c >> 8) & M) + ((d >> 8) & M) + R;
-    return ((e >> 2) & M) | (((o >> 2) & M) << 8);
-}
-
-H263_HD uint64_t load_u64_unaligned(const uint8_t *p)
-{
-    uint64_t v;
-    memcpy(&v, p, 8);
-    return v;
 }
 
 // idct.rs:39-48 BASIS_TABLE[freq][x] -- the reference's literals (not exact cosines).

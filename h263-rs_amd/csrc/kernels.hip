@@ -2,22 +2,11 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
 #include "kernels.h"
 
-#include <stdlib.h>
-
 #include "post_kernel.inl"
 #include "recon_kernel.inl"
 #include "synth.inl"
 
 namespace h263mi {
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
-// for every outstanding global load and store of the wave -- which would serialise the prefetch of
-// the next tile (and the write latency of the previous one) behind each barrier.  Global loads are
-// still waited for where their registers are first used (the compiler tracks vmcnt itself).
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 #if defined(H263MI_PROFILE_PHASES)
 // diagnosis build: wall-clock cycles (s_memtime) a wave spends in each phase of k_recon, summed over waves
@@ -115,20 +104,14 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
 {
-    static const uint32_t env_debug = [] {
-        const char *e = getenv("H263MI_DEBUG_RECON");
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    ReconArgs a = args;
-    a.debug_flags |= env_debug;
     const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures * (TILE_WAVES / RECON_HALVES / RECON_WAVES);
     const uint32_t chunk = (total + 7) / 8;
-    hipLaunchKernelGGL(k_recon, dim3(chunk * 8), dim3(RECON_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_recon, dim3(chunk * 8), dim3(RECON_THREADS), 0, stream, args);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
-// k_post: persistent, 256 threads, grid = 8 x (workgroups per XCD).
+// k_post: one wave per workgroup = one 128x32 tile; grid = 8 x (tiles per XCD).
 //
 // Work order is XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names
 // the group that shares an L2 -- a speed assumption only, never correctness), so XCD k walks the

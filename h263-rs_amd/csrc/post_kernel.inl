@@ -145,11 +145,6 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
 {
     const uint8_t *frame = a.frames + (size_t)pic * a.L.frame_bytes;
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
-#if defined(H263MI_DIAG_POST_NO_LOADS)                        // diagnosis build: compute and stores without the loads
-#pragma unroll
-    for (int q = 0; q < 4; q++) { r.y[q] = 0x40506070u + lane + sy; r.c[q] = (uint16_t)(0x8070 + lane); }
-    return;
-#endif
     {
         // uniform base + 32-bit per-lane offset: the loads use scalar-base addressing, no 64-bit VALU adds
         const int row = lane >> 3, col = (lane & 7) * 16;

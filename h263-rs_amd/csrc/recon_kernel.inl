@@ -9,21 +9,24 @@
 // the 8 macroblocks (a 128x8 luma strip + a 64x8 Cb strip), wave "bottom" owns Y2, Y3 and Cr.
 // That is 24 blocks and 3 x 64 eight-pixel row segments per wave; every luma row it stores is
 // one full 128-byte line.  A wave needs nothing from any other wave, so there is NO workgroup
-// barrier: hand-offs between lanes go through 6 KB of wave-private LDS and rely only on the
-// DS operations of one wave executing in order.  A workgroup is 4 such waves (8x2
-// macroblocks) purely so that the XCD-aware work order of kernels.hip keeps neighbours on
-// one L2.
+// barrier: hand-offs between lanes go through 5.8 KB of wave-private LDS and rely only on the
+// DS operations of one wave executing in order.  One wave is one workgroup (its LDS and
+// registers are released when it ends); the XCD-aware work order of kernels.hip keeps the four
+// waves of an 8x2-macroblock tile, and neighbouring tiles, on one L2.
 //
 // Wave timeline:
 //   records  : 8 records (256 B) -> LDS; list of blocks that need an IDCT (coded & !kill, or
-//              uncoded intra with non-zero DC) compacted in LDS; chroma vectors once per MB
+//              uncoded intra with non-zero DC) compacted in LDS; chroma vectors and the mask
+//              of inter macroblocks once per MB
 //   fetch    : ALL global loads are issued now, before any arithmetic: the reference rows of
-//              the lane's three segments (one unaligned 12-byte load per row, taps clamped to
-//              the picture) and the coefficient row of the first IDCT round
+//              the lane's three segments (one dword-aligned 12-byte load per row; rows nobody
+//              needs read offset 0; picture-edge segments load the window that holds all their
+//              clamped taps) and the coefficient row of the first IDCT round
 //   idct     : rounds of 8 blocks, 8 lanes per block, lane = one coefficient row: dequant,
 //              row pass T = C x B -> LDS; then lane = one pixel column: column of T (the
-//              LDS transposition), column pass, rounding -> residual strip (i16) in LDS
-//   output   : lane = 8 horizontal pixels: half-pel interpolation on packed bytes, + residual
+//              LDS transposition), column pass, rounding -> residual strip (i16) in LDS; both
+//              passes stop at the last non-zero coefficient column / row of the round
+//   output   : lane = 8 horizontal pixels: one branch-free half-pel form on packed bytes, + residual
 //              row (packed i16 add, saturate to u8), one 8-byte store
 //
 // Bit-exactness rules: f32 multiply and add are separately rounded

@@ -156,20 +156,23 @@ struct h263mi_batch {
     int ensure_host_staging(HostStaging &g2, size_t n_blocks)
     {
         const size_t total = (size_t)n * L.mbw * L.mbh;
-        if (!g2.h_mbs) {
-            HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
-            HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
-            HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
-        }
+        // each piece on its own, so that a failed allocation leaves nothing half-initialised for the next call
+        if (!g2.h_mbs) HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
+        if (!g2.d_mbs) HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
+        if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
+        if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
+        if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
         if (n_blocks > g2.cap_blocks) {
             if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
             if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
             g2.h_coeffs = nullptr; g2.d_coeffs = nullptr; g2.cap_blocks = 0;
             const size_t cap = n_blocks + n_blocks / 2 + 64;
             HIP_TRY(hipHostMalloc((void **)&g2.h_coeffs, cap * 128, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&g2.d_coeffs, cap * 128));
+            if (hipMalloc((void **)&g2.d_coeffs, cap * 128) != hipSuccess) {
+                (void)hipHostFree(g2.h_coeffs);
+                g2.h_coeffs = nullptr;
+                return H263MI_ERR_OUT_OF_MEMORY;
+            }
             g2.cap_blocks = cap;
         }
         return H263MI_OK;

@@ -92,7 +92,8 @@ struct h263mi_batch {
         MbRecord *h_mbs = nullptr, *d_mbs = nullptr;
         int16_t *h_coeffs = nullptr, *d_coeffs = nullptr;
         uint64_t *h_base = nullptr, *d_base = nullptr;
-        size_t cap_blocks = 0;
+        uint32_t *h_events = nullptr, *d_events = nullptr;   // sparse transport: rebased block offsets, then events
+        size_t cap_blocks = 0, cap_events = 0;
         hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
     } host_stg[2];
     unsigned host_slot = 0;
@@ -149,12 +150,23 @@ struct h263mi_batch {
             if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
             if (g2.h_base) (void)hipHostFree(g2.h_base);
             if (g2.d_base) (void)hipFree(g2.d_base);
+            if (g2.h_events) (void)hipHostFree(g2.h_events);
+            if (g2.d_events) (void)hipFree(g2.d_events);
             if (g2.done) (void)hipEventDestroy(g2.done);
         }
     }
 
-    int ensure_host_staging(HostStaging &g2, size_t n_blocks)
+    int ensure_host_staging(HostStaging &g2, size_t n_blocks, size_t n_event_words = 0)
     {
+        if (n_event_words > g2.cap_events) {
+            if (g2.h_events) (void)hipHostFree(g2.h_events);
+            if (g2.d_events) (void)hipFree(g2.d_events);
+            g2.h_events = nullptr; g2.d_events = nullptr; g2.cap_events = 0;
+            const size_t cap = n_event_words + n_event_words / 2 + 256;
+            HIP_TRY(hipHostMalloc((void **)&g2.h_events, cap * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&g2.d_events, cap * sizeof(uint32_t)));
+            g2.cap_events = cap;
+        }
         const size_t total = (size_t)n * L.mbw * L.mbh;
         // each piece on its own, so that a failed allocation leaves nothing half-initialised for the next call
         if (!g2.h_mbs) HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
@@ -162,14 +174,17 @@ struct h263mi_batch {
         if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
         if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
         if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
-        if (n_blocks > g2.cap_blocks) {
+        // with sparse transport the dense blocks exist on the device only (k_expand writes them)
+        if (n_blocks > g2.cap_blocks || (!n_event_words && !g2.h_coeffs)) {
             if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
             if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
-            g2.h_coeffs = nullptr; g2.d_coeffs = nullptr; g2.cap_blocks = 0;
-            const size_t cap = n_blocks + n_blocks / 2 + 64;
-            HIP_TRY(hipHostMalloc((void **)&g2.h_coeffs, cap * 128, hipHostMallocDefault));
+            g2.h_coeffs = nullptr; g2.d_coeffs = nullptr;
+            size_t cap = std::max(n_blocks, g2.cap_blocks);
+            cap = cap + cap / 2 + 64;
+            g2.cap_blocks = 0;
+            if (!n_event_words) HIP_TRY(hipHostMalloc((void **)&g2.h_coeffs, cap * 128, hipHostMallocDefault));
             if (hipMalloc((void **)&g2.d_coeffs, cap * 128) != hipSuccess) {
-                (void)hipHostFree(g2.h_coeffs);
+                if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
                 g2.h_coeffs = nullptr;
                 return H263MI_ERR_OUT_OF_MEMORY;
             }
@@ -335,7 +350,8 @@ struct h263mi_state {
     struct Staging {
         MbRecord *h_mbs = nullptr;  int16_t *h_coeffs = nullptr;     // pinned
         MbRecord *d_mbs = nullptr;  int16_t *d_coeffs = nullptr;
-        size_t cap_mbs = 0, cap_blocks = 0;
+        uint32_t *h_events = nullptr, *d_events = nullptr;           // sparse transport: block offsets, then events
+        size_t cap_mbs = 0, cap_blocks = 0, cap_events = 0;
         hipEvent_t done = nullptr;  // recorded after the kernel that reads the slot
     } stg[2];
     unsigned next_slot = 0;
@@ -348,6 +364,8 @@ struct h263mi_state {
             if (g.h_coeffs) (void)hipHostFree(g.h_coeffs);
             if (g.d_mbs) (void)hipFree(g.d_mbs);
             if (g.d_coeffs) (void)hipFree(g.d_coeffs);
+            if (g.h_events) (void)hipHostFree(g.h_events);
+            if (g.d_events) (void)hipFree(g.d_events);
             if (g.done) (void)hipEventDestroy(g.done);
             g = Staging();
         }
@@ -364,7 +382,8 @@ struct h263mi_state {
     }
 };
 
-static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n_blocks)
+// n_event_words > 0: sparse transport -- the dense blocks exist on the device only (k_expand writes them)
+static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n_blocks, size_t n_event_words)
 {
     if (n_mbs > g.cap_mbs) {
         if (g.h_mbs) (void)hipHostFree(g.h_mbs);
@@ -374,18 +393,34 @@ static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n
         HIP_TRY(hipMalloc((void **)&g.d_mbs, n_mbs * sizeof(MbRecord)));
         g.cap_mbs = n_mbs;
     }
-    if (n_blocks > g.cap_blocks) {
+    if (n_blocks > g.cap_blocks || (!n_event_words && !g.h_coeffs)) {
         if (g.h_coeffs) (void)hipHostFree(g.h_coeffs);
         if (g.d_coeffs) (void)hipFree(g.d_coeffs);
         g.h_coeffs = nullptr; g.d_coeffs = nullptr; g.cap_blocks = 0;
-        size_t cap = n_blocks + n_blocks / 2 + 64;
-        HIP_TRY(hipHostMalloc((void **)&g.h_coeffs, cap * 128, hipHostMallocDefault));
+        size_t cap = std::max(n_blocks, g.cap_blocks);
+        cap = cap + cap / 2 + 64;
+        if (!n_event_words) HIP_TRY(hipHostMalloc((void **)&g.h_coeffs, cap * 128, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&g.d_coeffs, cap * 128));
         g.cap_blocks = cap;
+    }
+    if (n_event_words > g.cap_events) {
+        if (g.h_events) (void)hipHostFree(g.h_events);
+        if (g.d_events) (void)hipFree(g.d_events);
+        g.h_events = nullptr; g.d_events = nullptr; g.cap_events = 0;
+        const size_t cap = n_event_words + n_event_words / 2 + 256;
+        HIP_TRY(hipHostMalloc((void **)&g.h_events, cap * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&g.d_events, cap * sizeof(uint32_t)));
+        g.cap_events = cap;
     }
     if (!g.done) HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     return H263MI_OK;
 }
+
+// state.rs:421-483 from host records; the coefficients come either as dense blocks (`coeffs`) or as events
+// (`first_event` + `events`, expanded on the device)
+static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
+                          const int16_t *coeffs, size_t n_coeff_blocks, const uint32_t *first_event, const uint32_t *events,
+                          size_t n_events);
 
 extern "C" {
 
@@ -445,42 +480,72 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
     return b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base);
 }
 
-int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
-                             const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks)
+}  // extern "C"
+
+// one picture per stream from per-stream host arrays; coefficients dense (`coeffs`) or as events (`first_event`,
+// `events`, `n_events`)
+static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
+                             const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks,
+                             const uint32_t *const *first_event, const uint32_t *const *events, const uint32_t *n_events)
 {
-    if (!b || !mbs || !n_mbs || !coeffs || !n_coeff_blocks || picture_type > H263MI_PICTURE_RESERVED)
+    const bool sparse = first_event != nullptr;
+    if (!b || !mbs || !n_mbs || !n_coeff_blocks || (!sparse && !coeffs) || (sparse && (!events || !n_events)) ||
+        picture_type > H263MI_PICTURE_RESERVED)
         return H263MI_ERR_INVALID_ARGUMENT;
     const size_t per = (size_t)b->L.mbw * b->L.mbh;
-    size_t blocks = 0;
+    size_t blocks = 0, n_ev = 0;
     for (uint32_t i = 0; i < b->n; i++) {
-        if (n_mbs[i] > per || (n_mbs[i] && !mbs[i]) || (n_coeff_blocks[i] && !coeffs[i])) return H263MI_ERR_INVALID_ARGUMENT;
+        if (n_mbs[i] > per || (n_mbs[i] && !mbs[i])) return H263MI_ERR_INVALID_ARGUMENT;
+        if (n_coeff_blocks[i]) {
+            if (!sparse && !coeffs[i]) return H263MI_ERR_INVALID_ARGUMENT;
+            if (sparse && (!first_event[i] || first_event[i][0] != 0 || first_event[i][n_coeff_blocks[i]] != n_events[i] ||
+                           (n_events[i] && !events[i])))
+                return H263MI_ERR_INVALID_ARGUMENT;
+        }
         blocks += n_coeff_blocks[i];
+        if (sparse) n_ev += n_events[i];
     }
+    if (blocks > 0xffffffffu / 8u || n_ev > 0xffffffffu) return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
     h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];
-    RC_TRY(b->ensure_host_staging(g2, blocks ? blocks : 1));
+    const size_t event_words = sparse ? blocks + 1 + n_ev : 0;
+    RC_TRY(b->ensure_host_staging(g2, blocks ? blocks : 1, event_words));
     HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
 
     MbRecord pad;                                // state.rs:421-427: Inter, mv (0,0), nothing coded
     memset(&pad, 0, sizeof pad);
     pad.mb_type = H263MI_MB_INTER;
     pad.quant = 1;
+    std::vector<uint32_t> ev_base(b->n + 1, 0);
     size_t at = 0;
     for (uint32_t i = 0; i < b->n; i++) {        // coeff_index of stream i counts from its own first block
         g2.h_base[i] = at;
         at += n_coeff_blocks[i];
+        ev_base[i + 1] = ev_base[i] + (sparse ? n_events[i] : 0);
     }
+    uint32_t *h_first = g2.h_events, *h_ev = sparse ? g2.h_events + blocks + 1 : nullptr;
+    bool offsets_ok = true;
     // packing is a host memcpy of every record byte: a few threads, or one core caps the rate below the PCIe link
     auto pack = [&](uint32_t first, uint32_t last) {
         for (uint32_t i = first; i < last; i++) {
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
             if (n_mbs[i]) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
             for (size_t k = n_mbs[i]; k < per; k++) dst[k] = pad;
-            if (n_coeff_blocks[i]) memcpy(g2.h_coeffs + g2.h_base[i] * 64, coeffs[i], (size_t)n_coeff_blocks[i] * 128);
+            if (!n_coeff_blocks[i]) continue;
+            if (!sparse) {
+                memcpy(g2.h_coeffs + g2.h_base[i] * 64, coeffs[i], (size_t)n_coeff_blocks[i] * 128);
+            } else {
+                uint32_t *fo = h_first + g2.h_base[i];
+                for (uint32_t k = 0; k < n_coeff_blocks[i]; k++) {
+                    if (first_event[i][k] > first_event[i][k + 1]) offsets_ok = false;    // (benign race: only ever set to false)
+                    fo[k] = first_event[i][k] + ev_base[i];
+                }
+                if (n_events[i]) memcpy(h_ev + ev_base[i], events[i], (size_t)n_events[i] * sizeof(uint32_t));
+            }
         }
     };
-    const size_t bytes = (size_t)b->n * per * sizeof(MbRecord) + blocks * 128;
+    const size_t bytes = (size_t)b->n * per * sizeof(MbRecord) + (sparse ? event_words * 4 : blocks * 128);
     const uint32_t n_thr = bytes < (4u << 20) ? 1u : std::min<uint32_t>({8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
     if (n_thr <= 1) {
         pack(0, b->n);
@@ -490,14 +555,42 @@ int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             pool.emplace_back(pack, (uint32_t)((uint64_t)b->n * t / n_thr), (uint32_t)((uint64_t)b->n * (t + 1) / n_thr));
         for (std::thread &t : pool) t.join();
     }
+    if (!offsets_ok) return H263MI_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, (size_t)b->n * per * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
-    if (blocks) HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
+    if (sparse && blocks) {
+        h_first[blocks] = (uint32_t)n_ev;
+        HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+        ExpandArgs ea{};
+        ea.block_first_event = g2.d_events;
+        ea.events = g2.d_events + blocks + 1;
+        ea.coeffs = g2.d_coeffs;
+        ea.n_blocks = (uint32_t)blocks;
+        HIP_TRY(launch_expand(ea, b->stream));
+    } else if (blocks) {
+        HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
+    }
     b->coeff_pool_blocks = blocks;
     RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base));
     HIP_TRY(hipEventRecord(g2.done, b->stream));
     b->host_slot++;
     return H263MI_OK;
+}
+
+extern "C" {
+
+int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
+                             const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks)
+{
+    return batch_submit_host(b, picture_type, mbs, n_mbs, coeffs, n_coeff_blocks, nullptr, nullptr, nullptr);
+}
+
+int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
+                                    const uint32_t *n_mbs, const uint32_t *const *block_first_event,
+                                    const uint32_t *n_coeff_blocks, const uint32_t *const *events, const uint32_t *n_events)
+{
+    if (!block_first_event) return H263MI_ERR_INVALID_ARGUMENT;
+    return batch_submit_host(b, picture_type, mbs, n_mbs, nullptr, n_coeff_blocks, block_first_event, events, n_events);
 }
 
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)
@@ -602,10 +695,21 @@ int h263mi_state_cleanup_buffers(h263mi_state *s)
     return s ? H263MI_OK : H263MI_ERR_INVALID_ARGUMENT;
 }
 
-int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
-                          const int16_t *coeffs, size_t n_coeff_blocks)
+}  // extern "C"
+
+static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
+                          const int16_t *coeffs, size_t n_coeff_blocks, const uint32_t *first_event, const uint32_t *events,
+                          size_t n_events)
 {
-    if (!s || !desc || (!mbs && n_mbs) || (!coeffs && n_coeff_blocks)) return H263MI_ERR_INVALID_ARGUMENT;
+    const bool sparse = first_event != nullptr;
+    if (!s || !desc || (!mbs && n_mbs) || (!sparse && !coeffs && n_coeff_blocks) || (sparse && !events && n_events))
+        return H263MI_ERR_INVALID_ARGUMENT;
+    if (sparse && n_coeff_blocks) {
+        // offsets must be monotone and end at n_events: checked here, the kernel trusts them
+        if (first_event[0] != 0 || first_event[n_coeff_blocks] != n_events) return H263MI_ERR_INVALID_ARGUMENT;
+        for (size_t i = 0; i < n_coeff_blocks; i++)
+            if (first_event[i] > first_event[i + 1]) return H263MI_ERR_INVALID_ARGUMENT;
+    }
     if (!desc->width || !desc->height) return H263MI_ERR_PICTURE_FORMAT_INVALID;
     if (desc->picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;
     const FrameLayout L = make_layout(desc->width, desc->height);
@@ -639,7 +743,8 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, cons
     }
     h263mi_batch *b = s->b;
     h263mi_state::Staging &g2 = s->stg[s->next_slot & 1];
-    RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1));
+    const size_t event_words = sparse ? n_coeff_blocks + 1 + n_events : 0;
+    RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1, event_words));
     HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
 
     memcpy(g2.h_mbs, mbs, n_mbs * sizeof(MbRecord));
@@ -650,10 +755,21 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, cons
         pad.quant = 1;
         g2.h_mbs[i] = pad;
     }
-    if (n_coeff_blocks) memcpy(g2.h_coeffs, coeffs, n_coeff_blocks * 128);
     HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, total * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
-    if (n_coeff_blocks)
+    if (sparse && n_coeff_blocks) {
+        memcpy(g2.h_events, first_event, (n_coeff_blocks + 1) * sizeof(uint32_t));
+        if (n_events) memcpy(g2.h_events + n_coeff_blocks + 1, events, n_events * sizeof(uint32_t));
+        HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+        ExpandArgs ea{};
+        ea.block_first_event = g2.d_events;
+        ea.events = g2.d_events + n_coeff_blocks + 1;
+        ea.coeffs = g2.d_coeffs;
+        ea.n_blocks = (uint32_t)n_coeff_blocks;
+        HIP_TRY(launch_expand(ea, b->stream));
+    } else if (n_coeff_blocks) {
+        memcpy(g2.h_coeffs, coeffs, n_coeff_blocks * 128);
         HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, n_coeff_blocks * 128, hipMemcpyHostToDevice, b->stream));
+    }
 
     b->coeff_pool_blocks = n_coeff_blocks;
     RC_TRY(b->submit(desc->picture_type, g2.d_mbs, g2.d_coeffs, nullptr));
@@ -664,16 +780,35 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, cons
     return H263MI_OK;
 }
 
+extern "C" {
+
+int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
+                          const int16_t *coeffs, size_t n_coeff_blocks)
+{
+    return submit_records(s, desc, mbs, n_mbs, coeffs, n_coeff_blocks, nullptr, nullptr, 0);
+}
+
+int h263mi_submit_picture_events(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs,
+                                 size_t n_mbs, const uint32_t *block_first_event, size_t n_coeff_blocks,
+                                 const uint32_t *events, size_t n_events)
+{
+    if (!block_first_event) return H263MI_ERR_INVALID_ARGUMENT;
+    if (n_coeff_blocks > 0xffffffffu / 8u) return H263MI_ERR_INVALID_ARGUMENT;
+    return submit_records(s, desc, mbs, n_mbs, nullptr, n_coeff_blocks, block_first_event, events, n_events);
+}
+
 int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len, size_t *consumed)
 {
     if (!s || (!data && len)) return H263MI_ERR_INVALID_ARGUMENT;
     if (consumed) *consumed = 0;
     // serial half on the host (state.rs:143-427) ...
     bits::ParsedPicture pic;
+    pic.want_dense = false;                              // the coefficients travel as events
     RC_TRY(bits::parse_picture(data, len, s->options, &s->parser_ctx, pic));
     // ... everything from the cut line on (state.rs:421-483) on the GPU.  Nothing has touched the state so
     // far, so every error above leaves it unchanged, like the reader transaction of state.rs:142.
-    RC_TRY(h263mi_submit_picture(s, &pic.desc, pic.mbs.data(), pic.mbs.size(), pic.coeffs.data(), pic.coeffs.size() / 64));
+    RC_TRY(h263mi_submit_picture_events(s, &pic.desc, pic.mbs.data(), pic.mbs.size(), pic.block_first_event.data(),
+                                        pic.n_coded_blocks, pic.events.data(), pic.events.size()));
     s->parser_ctx = pic.next;
     if (consumed) *consumed = pic.bits_consumed / 8;     // reader.commit() drains whole bytes (reader.rs:391-394)
     return H263MI_OK;

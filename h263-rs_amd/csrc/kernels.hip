@@ -2,6 +2,7 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
 #include "kernels.h"
 
+#include "expand_kernel.inl"
 #include "post_kernel.inl"
 #include "recon_kernel.inl"
 #include "synth.inl"
@@ -186,6 +187,23 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream)
     const uint32_t groups_y = (args.tiles_y + POST_GROUP - 1) / POST_GROUP;
     const uint32_t units = args.tiles_x * groups_y * args.n_pictures * (POST_GROUP / POST_WAVES), chunk = (units + 7) / 8;
     hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// k_expand: sparse coefficient events -> dense blocks (expand_kernel.inl)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EXPAND_THREADS) void k_expand(ExpandArgs a)
+{
+    const uint32_t g = blockIdx.x * EXPAND_THREADS + threadIdx.x;
+    expand_lane(a.block_first_event, a.events, a.coeffs, a.n_blocks, g >> 3, (int)(g & 7));
+}
+
+hipError_t launch_expand(const ExpandArgs &args, hipStream_t stream)
+{
+    if (!args.n_blocks) return hipSuccess;
+    const uint32_t groups = (args.n_blocks * 8 + EXPAND_THREADS - 1) / EXPAND_THREADS;
+    hipLaunchKernelGGL(k_expand, dim3(groups), dim3(EXPAND_THREADS), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -27,6 +27,21 @@ ERR_INVALID_ARGUMENT = -100
 ERR_NO_DEVICE = -101
 ERR_NO_PICTURE = -104
 
+def events_from_dense(coeffs, intra_blocks=None):
+    """dense (n, 64) LEVEL blocks -> (block_first_event, events) of h263mi_submit_picture_events.  intra_blocks: mask
+    of blocks whose element 0 is not a TCOEF (the DC of an intra block travels in the record)."""
+    c = np.ascontiguousarray(coeffs, np.int16).reshape(-1, 64)
+    nz = c != 0
+    if intra_blocks is not None:
+        nz[np.asarray(intra_blocks, bool), 0] = False
+    counts = nz.sum(axis=1)
+    first = np.zeros(len(c) + 1, np.uint32)
+    np.cumsum(counts, out=first[1:])
+    blk, pos = np.nonzero(nz)
+    ev = (c[blk, pos].astype(np.uint16).astype(np.uint32) << 16) | pos.astype(np.uint32)
+    return first, ev
+
+
 SORENSON_SPARK_BITSTREAM = 1
 USE_SCALABILITY_MODE = 2
 PICTURE_I, PICTURE_P, PICTURE_DISPOSABLE_P = 0, 1, 2
@@ -49,7 +64,7 @@ EXPORTS = [
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
-    "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_submit_host",
+    "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_submit_host", "h263mi_submit_picture_events", "h263mi_batch_submit_host_events",
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
     "h263mi_synth_picture_host", "h263mi_synth_batch_device",
@@ -115,6 +130,7 @@ def lib():
         L.h263mi_state_reset.argtypes = [vp]
         L.h263mi_state_cleanup_buffers.argtypes = [vp]
         L.h263mi_submit_picture.argtypes = [vp, C.POINTER(PictureDesc), vp, sz, vp, sz]
+        L.h263mi_submit_picture_events.argtypes = [vp, C.POINTER(PictureDesc), vp, sz, vp, sz, vp, sz]
         L.h263mi_decode_next_picture.argtypes = [vp, vp, sz, C.POINTER(sz)]
         L.h263mi_parse_picture_header.argtypes = [vp, vp, sz, C.POINTER(PictureDesc)]
         L.h263mi_get_last_picture.argtypes = [vp, C.POINTER(FrameView)]
@@ -130,6 +146,7 @@ def lib():
         L.h263mi_batch_mbs_per_picture.restype = u32
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
         L.h263mi_batch_submit_host.argtypes = [vp, u8, vp, vp, vp, vp]
+        L.h263mi_batch_submit_host_events.argtypes = [vp, u8, vp, vp, vp, vp, vp, vp]
         L.h263mi_batch_render_rgba.argtypes = [vp, u8, vp, vp]
         L.h263mi_batch_sync.argtypes = [vp]
         L.h263mi_batch_reset.argtypes = [vp]
@@ -261,6 +278,17 @@ class H263State:
         _check(lib().h263mi_submit_picture(self._h, C.byref(d), _p(mbs) if mbs.size else None, mbs.size,
                                            _p(coeffs) if coeffs.size else None, coeffs.shape[0]), "submit_picture")
 
+    def submit_picture_events(self, width, height, mbs, block_first_event, events, picture_type=PICTURE_I,
+                              temporal_reference=0, pquant=1, use_deblocker=0):
+        """submit_picture with sparse coefficient transport (h263mi_submit_picture_events)."""
+        mbs = np.ascontiguousarray(mbs, dtype=MB_RECORD_DTYPE)
+        first = np.ascontiguousarray(block_first_event, dtype=np.uint32)
+        ev = np.ascontiguousarray(events, dtype=np.uint32)
+        d = PictureDesc(width, height, picture_type, pquant, use_deblocker, 0, temporal_reference, 0)
+        _check(lib().h263mi_submit_picture_events(self._h, C.byref(d), _p(mbs) if mbs.size else None, mbs.size, _p(first),
+                                                  first.size - 1, _p(ev) if ev.size else None, ev.size),
+               "submit_picture_events")
+
     def decode_next_picture(self, data):
         data = np.frombuffer(bytes(data), dtype=np.uint8)
         used = C.c_size_t(0)
@@ -374,6 +402,20 @@ class Batch:
         nm = (C.c_uint32 * n)(*[len(m) for m in mbs])
         nc = (C.c_uint32 * n)(*[len(c) for c in cos])
         _check(lib().h263mi_batch_submit_host(self._h, picture_type, pm, nm, pc, nc), "batch_submit_host")
+
+    def submit_host_events(self, picture_type, mbs_list, first_list, events_list):
+        """submit_host with sparse coefficient transport: per stream (block_first_event, events) arrays"""
+        n = len(mbs_list)
+        mbs = [np.ascontiguousarray(m, MB_RECORD_DTYPE) for m in mbs_list]
+        fs = [np.ascontiguousarray(f, np.uint32) for f in first_list]
+        evs = [np.ascontiguousarray(e, np.uint32) for e in events_list]
+        pm = (C.c_void_p * n)(*[m.ctypes.data if m.size else None for m in mbs])
+        pf = (C.c_void_p * n)(*[f.ctypes.data for f in fs])
+        pe = (C.c_void_p * n)(*[e.ctypes.data if e.size else None for e in evs])
+        nm = (C.c_uint32 * n)(*[len(m) for m in mbs])
+        nb = (C.c_uint32 * n)(*[len(f) - 1 for f in fs])
+        ne = (C.c_uint32 * n)(*[len(e) for e in evs])
+        _check(lib().h263mi_batch_submit_host_events(self._h, picture_type, pm, nm, pf, nb, pe, ne), "batch_submit_host_events")
 
     def render_rgba(self, strength, d_rgba, d_deblocked=None):
         _check(lib().h263mi_batch_render_rgba(self._h, strength, d_rgba, d_deblocked), "batch_render_rgba")

@@ -644,7 +644,10 @@ bool resync_ends_picture(BitReader &r, int &rc)
 // ---------------------------------------------------------------------------------------------------
 int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, const ParserContext *ctx, ParsedPicture &out)
 {
+    const bool want_dense = out.want_dense;
     out = ParsedPicture();
+    out.want_dense = want_dense;
+    out.block_first_event.push_back(0);
     BitReader r(data, len);
     PictureHeader hdr;
     bool is_picture = false;
@@ -775,7 +778,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             }
             rec.mb_type = (uint8_t)mb_type;
             rec.quant = (uint8_t)in_force_quantizer;
-            rec.coeff_index = (uint32_t)(out.coeffs.size() / 64);
+            rec.coeff_index = (uint32_t)out.n_coded_blocks;
             const int coded[6] = {(luma >> 3) & 1, (luma >> 2) & 1, (luma >> 1) & 1, luma & 1, cb, cr};
             for (int b = 0; b < 6; b++) {                                      // state.rs:287-381
                 ParsedBlock blk;
@@ -785,16 +788,20 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 if (!coded[b]) continue;
                 rec.cbp |= (uint8_t)(1u << b);
                 const size_t base = out.coeffs.size();
-                out.coeffs.resize(base + 64, 0);
+                if (want_dense) out.coeffs.resize(base + 64, 0);
                 // run-length expansion + de-zigzag of inverse_rle (rle.rs:117-136); dequantisation is left
                 // to the GPU.  A run that walks past zigzag 63 voids the block (rle.rs:125-127).
                 size_t zz = intra ? 1 : 0;
                 for (int t = 0; t < blk.n_tcoef; t++) {
                     zz += blk.tcoef[t].run;
                     if (zz >= 64) { rec.kill |= (uint8_t)(1u << b); break; }
-                    out.coeffs[base + kZigzagRaster[zz]] = blk.tcoef[t].level;
+                    const uint32_t pos = kZigzagRaster[zz];
+                    if (want_dense) out.coeffs[base + pos] = blk.tcoef[t].level;
+                    out.events.push_back(((uint32_t)(uint16_t)blk.tcoef[t].level << 16) | pos);
                     zz++;
                 }
+                out.n_coded_blocks++;
+                out.block_first_event.push_back((uint32_t)out.events.size());
             }
         }
         if (predictor_vectors.size() / 4 >= total) {

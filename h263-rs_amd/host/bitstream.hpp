@@ -173,7 +173,11 @@ int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserCo
 struct ParsedPicture {
     h263mi_picture_desc desc{};
     std::vector<h263mi_mb_record> mbs;     // the macroblocks present in the bitstream (<= mbw*mbh)
-    std::vector<int16_t> coeffs;           // 64 per coded block, raster order
+    std::vector<int16_t> coeffs;           // 64 per coded block, raster order (only with want_dense)
+    // the same coefficients as events, level << 16 | raster position, block k = [block_first_event[k], [k+1])
+    std::vector<uint32_t> block_first_event, events;
+    bool want_dense = true;                // set to false before parsing to skip the dense blocks
+    size_t n_coded_blocks = 0;
     size_t bits_consumed = 0;
     ParserContext next;                    // the context once this picture has been decoded successfully
 };

@@ -171,11 +171,25 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc,
                           const int16_t *coeffs, size_t n_coeff_blocks);
 
 /*
+ * The same with sparse coefficient transport: instead of a dense 128-byte block per coded block, one 32-bit
+ * event per non-zero LEVEL, `(uint16_t)level << 16 | position` with position = x + 8*y (the de-zigzagged place,
+ * DEZIGZAG_MAPPING rle.rs:6-71; an intra block's DC is not an event, it travels in the record).  Coded block k
+ * (the numbering of coeff_index) owns events [block_first_event[k], block_first_event[k+1]); the array has
+ * n_coeff_blocks + 1 entries, starts at 0 and ends at n_events.  A typical P picture needs a quarter of the
+ * bytes of the dense form over PCIe; a small kernel rebuilds the dense blocks in device memory.
+ */
+#define H263MI_EVENT(position, level) (((uint32_t)(uint16_t)(int16_t)(level) << 16) | ((uint32_t)(position) & 63u))
+int h263mi_submit_picture_events(h263mi_state *s, const h263mi_picture_desc *desc,
+                                 const h263mi_mb_record *mbs, size_t n_mbs,
+                                 const uint32_t *block_first_event, size_t n_coeff_blocks,
+                                 const uint32_t *events, size_t n_events);
+
+/*
  * H263State::decode_next_picture(reader)  state.rs:138-141, over a byte buffer holding
  * one coded picture (Ruffle hands one FLV video tag per reader).  `*consumed` receives the
  * bytes used.  The serial parse runs on the host (h263-rs_amd/host/bitstream.cpp: Sorenson Spark and ITU-T H.263
  * PTYPE / PLUSPTYPE headers, MCBPC/CBPY/MVD/TCOEF tables, Annex D vectors, motion vector prediction, the
- * start-code resynchronisation of state.rs:387-408) and feeds h263mi_submit_picture.  What the reference leaves
+ * start-code resynchronisation of state.rs:387-408) and feeds h263mi_submit_picture_events.  What the reference leaves
  * unimplemented (GOB headers, PB / B / EI / EP macroblocks, Annex T, reference picture resampling, back-channel
  * messages) returns H263MI_ERR_UNIMPLEMENTED_DECODING here too.  On any error the state -- including what it
  * remembers of the last picture header -- is unchanged.
@@ -270,6 +284,12 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
 int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type,
                              const h263mi_mb_record *const *mbs, const uint32_t *n_mbs,
                              const int16_t *const *coeffs, const uint32_t *n_coeff_blocks);
+/* ... and with sparse coefficient transport (see h263mi_submit_picture_events): block_first_event[s] has
+ * n_coeff_blocks[s] + 1 entries counting from 0, events[s] has n_events[s] entries. */
+int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
+                                    const h263mi_mb_record *const *mbs, const uint32_t *n_mbs,
+                                    const uint32_t *const *block_first_event, const uint32_t *n_coeff_blocks,
+                                    const uint32_t *const *events, const uint32_t *n_events);
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_sync(h263mi_batch *b);
 int h263mi_batch_reset(h263mi_batch *b);

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "../../h263-rs_amd/csrc/post_kernel.inl"
+#include "../../h263-rs_amd/csrc/expand_kernel.inl"
 #include "../../h263-rs_amd/csrc/recon_kernel.inl"
 #include "../../h263-rs_amd/csrc/synth.inl"
 
@@ -165,5 +166,12 @@ int sim_quartet_sweep(void (*ref)(uint8_t *, uint8_t *, uint8_t *, uint8_t *, ui
                         }
                     }
     return bad;
+}
+
+// k_expand: every (block, row) lane of the grid
+void sim_expand(const uint32_t *first, const uint32_t *events, int16_t *coeffs, uint32_t n_blocks)
+{
+    const uint32_t groups = (n_blocks * 8 + EXPAND_THREADS - 1) / EXPAND_THREADS;
+    for (uint32_t g = 0; g < groups * EXPAND_THREADS; g++) expand_lane(first, events, coeffs, n_blocks, g >> 3, (int)(g & 7));
 }
 }

@@ -413,10 +413,56 @@ def test_batch_submit_host_matches_the_oracle_per_stream():
                     c = c[:0]
             mbs.append(m)
             cos.append(c)
-        b.submit_host(h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, mbs, cos)
+        pt = h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P
+        if f & 1:                                                # odd pictures through the sparse transport
+            fe = []
+            for m, c in zip(mbs, cos):
+                intra = np.zeros(len(c), bool)
+                for r in m:
+                    if r["mb_type"] in (3, 4):
+                        k = bin(int(r["cbp"])).count("1")
+                        intra[int(r["coeff_index"]):int(r["coeff_index"]) + k] = True
+                fe.append(h263mi.events_from_dense(c, intra))
+            b.submit_host_events(pt, mbs, [x[0] for x in fe], [x[1] for x in fe])
+        else:
+            b.submit_host(pt, mbs, cos)
         b.sync()
         for s in range(n):
             rc, refs[s] = orc.decode_picture(w, h, mbs[s], cos[s], refs[s])
             assert rc == 0
             assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
     b.close()
+
+
+@pytest.mark.parametrize("w,h", [(176, 144), (100, 60), (16, 16), (320, 240)])
+def test_submit_picture_events_equals_dense_submit(w, h):
+    """sparse coefficient transport (k_expand) against the oracle, incl. blocks without any event, an intra block
+    whose element 0 is set in the dense form (ignored there, absent here), and duplicate positions"""
+    st = h263mi.H263State()
+    mbs, co = recgen.intra_picture(w, h, seed=w + 1, max_level=127)
+    intra_blk = np.ones(len(co), bool)
+    first, ev = h263mi.events_from_dense(co, intra_blk)
+    st.submit_picture_events(w, h, mbs, first, ev, h263mi.PICTURE_I)
+    rc, want = orc.decode_picture(w, h, mbs, co, None)
+    assert_planes_equal(st.get_last_picture().as_yuv(), want, "I")
+    for f in range(3):
+        mbs, co = recgen.inter_picture(w, h, seed=f + h, mv_range=50, p_4v=0.3, p_intra=0.2, p_coded=0.5, quant=9,
+                                       max_level=1023, sparse_low=bool(f & 1))
+        # which dense blocks belong to intra macroblocks
+        intra_blk = np.zeros(len(co), bool)
+        for m in mbs:
+            if m["mb_type"] in (3, 4):
+                n = bin(int(m["cbp"])).count("1")
+                intra_blk[int(m["coeff_index"]):int(m["coeff_index"]) + n] = True
+        first, ev = h263mi.events_from_dense(co, intra_blk)
+        st.submit_picture_events(w, h, mbs, first, ev, h263mi.PICTURE_P, temporal_reference=f + 1)
+        rc, want = orc.decode_picture(w, h, mbs, co, want)
+        assert_planes_equal(st.get_last_picture().as_yuv(), want, "P%d" % f)
+    # malformed offsets are rejected before anything is touched
+    bad = first.copy()
+    if len(bad) > 2:
+        bad[1] = bad[-1] + 5
+        with pytest.raises(h263mi.H263Error):
+            st.submit_picture_events(w, h, mbs, bad, ev, h263mi.PICTURE_P)
+        assert_planes_equal(st.get_last_picture().as_yuv(), want, "after error")
+    st.close()

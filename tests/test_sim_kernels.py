@@ -194,3 +194,27 @@ def test_quartet_arithmetic_matches_the_oracle_for_every_difference(floor_sem):
     L.sim_quartet_sweep.restype = C.c_int
     bad = L.sim_quartet_sweep(C.cast(ref, C.c_void_p), floor_sem, first)
     assert bad == 0, (bad, list(first))
+
+
+def test_expand_events_rebuilds_the_dense_blocks():
+    """k_expand (sparse coefficient transport): events -> dense blocks, every byte of the pool written"""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, simlib.os.path.join(simlib.HERE, "..", "h263-rs_amd"))
+    import h263mi
+    rng = np.random.default_rng(4)
+    dense = np.zeros((37, 64), np.int16)
+    for b in range(37):
+        k = int(rng.integers(0, 65)) if b % 5 else 0           # some blocks without any event
+        pos = rng.choice(64, size=k, replace=False)
+        lv = rng.integers(-1023, 1024, size=k)
+        lv[lv == 0] = 7
+        dense[b, pos] = lv
+    first, ev = h263mi.events_from_dense(dense)
+    out = np.full((37, 64), 0x5A5A, np.int16)
+    L = simlib.lib()
+    L.sim_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.sim_expand.restype = None
+    evp = ev if ev.size else np.zeros(1, np.uint32)
+    L.sim_expand(first.ctypes.data, evp.ctypes.data, out.ctypes.data, 37)
+    assert (out == dense).all()

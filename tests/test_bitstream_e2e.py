@@ -10,24 +10,18 @@ import sorenson_enc as enc
 from oracle import oracle as orc
 
 
-def quant_walk(rng, n, start):
-    q, out = start, []
-    for _ in range(n):
-        q = int(np.clip(q + rng.choice([0, 0, 0, -2, -1, 1, 2]), 1, 31))
-        out.append(q)
-    return out
-
-
 def make_codable(mbs, pquant, seed, picture_type):
     """Give the records a quantiser walk DQUANT can express and the Q / non-Q types that go with it."""
     rng = np.random.default_rng(seed)
     mbs = mbs.copy()
     q = pquant
-    for i, nq in enumerate(quant_walk(rng, len(mbs), pquant)):
+    for i in range(len(mbs)):
         m = mbs[i]
         t = int(m["mb_type"])
         intra, four = t in (3, 4), t in (2, 5)
         uncoded = picture_type != 0 and not intra and int(m["cbp"]) == 0 and not np.asarray(m["mv"]).any()
+        step = int(rng.choice([0, 0, 0, -2, -1, 1, 2]))
+        nq = int(np.clip(q + step, 1, 31))           # always within DQUANT's reach of the quantiser in force
         if uncoded:
             nq = q                                   # COD = 1 carries no DQUANT
             four = False

@@ -76,7 +76,7 @@ struct h263mi_batch {
     // post(i) reads set i; recon(i+1) reads set i and overwrites the set of picture i-1, which post(i-1) must have
     // finished reading -- both dependencies are HIP events.
     hipStream_t post_stream = nullptr;
-    hipEvent_t ev_recon_done = nullptr, ev_post_done = nullptr;
+    hipEvent_t ev_recon_done = nullptr, ev_post_done[2] = {nullptr, nullptr};   // post events per frame set
     bool overlap_post = false;
     uint32_t n = 0;
     FrameLayout L{};
@@ -139,7 +139,8 @@ struct h263mi_batch {
             (void)hipStreamDestroy(post_stream);
         }
         if (ev_recon_done) (void)hipEventDestroy(ev_recon_done);
-        if (ev_post_done) (void)hipEventDestroy(ev_post_done);
+        for (hipEvent_t e : ev_post_done)
+            if (e) (void)hipEventDestroy(e);
         if (d_status) (void)hipFree(d_status);
         if (h_status) (void)hipHostFree(h_status);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -236,7 +237,8 @@ struct h263mi_batch {
         a.has_ref = (has_ref && cur >= 0) ? 1u : 0u;
         a.tiles_x = recon_tiles_x(L);
         a.tiles_y = recon_tiles_y(L);
-        if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done, 0));   // the set being overwritten was read by post(i-1)
+        // the set being overwritten was last read by the post-processing of the picture before the last one
+        if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out], 0));
         RC_TRY(time_begin(0));
         HIP_TRY(launch_recon(a, stream));
         RC_TRY(time_end(0));
@@ -266,7 +268,7 @@ struct h263mi_batch {
         RC_TRY(time_begin(1));
         HIP_TRY(launch_post(a, stream_of(1)));
         RC_TRY(time_end(1));
-        if (overlap_post) HIP_TRY(hipEventRecord(ev_post_done, post_stream));
+        if (overlap_post) HIP_TRY(hipEventRecord(ev_post_done[cur], post_stream));
         return H263MI_OK;
     }
 
@@ -323,7 +325,8 @@ static int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi
         b->overlap_post = true;
         if (hipStreamCreateWithFlags(&b->post_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_recon_done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&b->ev_post_done, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&b->ev_post_done[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_post_done[1], hipEventDisableTiming) != hipSuccess)
             rc = H263MI_ERR_HIP;
     }
     if (rc == H263MI_OK) rc = b->alloc(n_streams, w, h);

@@ -466,3 +466,36 @@ def test_submit_picture_events_equals_dense_submit(w, h):
             st.submit_picture_events(w, h, mbs, bad, ev, h263mi.PICTURE_P)
         assert_planes_equal(st.get_last_picture().as_yuv(), want, "after error")
     st.close()
+
+
+def test_batch_overlap_mode_gives_the_same_pictures():
+    """H263MI_CFG_OVERLAP_POST: k_post on a second stream under the next k_recon; the frame-set dependencies are HIP
+    events.  Several pictures back to back without a sync in between, RGBA of every picture checked."""
+    w, h, n = 176, 144, 3
+    b = h263mi.Batch(n, w, h, overlap_post=True)
+    cw = (w + 1) // 2
+    refs = [None] * n
+    d_rgba = [h263mi.DeviceBuffer(n * w * h * 4) for _ in range(5)]
+    want_rgba = []
+    for f in range(5):
+        mbs, cos = [], []
+        for s in range(n):
+            if f == 0:
+                m, c = recgen.intra_picture(w, h, seed=7 * s + 2)
+            else:
+                m, c = recgen.inter_picture(w, h, seed=50 * f + s, mv_range=40, p_4v=0.3, p_coded=0.4, quant=6)
+            mbs.append(m)
+            cos.append(c)
+            rc, refs[s] = orc.decode_picture(w, h, m, c, refs[s])
+        b.submit_host(h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, mbs, cos)
+        b.render_rgba(5, d_rgba[f].ptr)
+        want_rgba.append([orc.yuv420_to_rgba(*(orc.deblock(p, pw, 5) for p, pw in zip(refs[s], (w, cw, cw))), w)
+                          for s in range(n)])
+    b.sync()
+    for f in range(5):
+        got = d_rgba[f].download().reshape(n, -1)
+        for s in range(n):
+            assert (got[s] == want_rgba[f][s].reshape(-1)).all(), (f, s)
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), refs[s], "stream %d" % s)
+    b.close()

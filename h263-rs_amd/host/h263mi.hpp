@@ -113,6 +113,15 @@ public:
         check(h263mi_submit_picture(s_, &desc, mbs.data(), mbs.size(), coeffs.data(), coeffs.size() / 64));
     }
 
+    // the same with sparse coefficient transport: one event (level << 16 | x + 8y) per non-zero LEVEL
+    void submit_picture_events(const h263mi_picture_desc &desc, const std::vector<h263mi_mb_record> &mbs,
+                               const std::vector<uint32_t> &block_first_event, const std::vector<uint32_t> &events)
+    {
+        check(h263mi_submit_picture_events(s_, &desc, mbs.data(), mbs.size(), block_first_event.data(),
+                                           block_first_event.empty() ? 0 : block_first_event.size() - 1, events.data(),
+                                           events.size()));
+    }
+
     // consumer post-processing of the last picture: deblock x3 (strength 0 = off) + BT.601
     std::vector<uint8_t> render_rgba(uint8_t strength) const
     {

@@ -89,6 +89,7 @@ struct ReconArgs {
     uint32_t mbs_per_picture;
     uint32_t has_ref;            // 0: inter macroblocks are an error
     uint32_t tiles_x, tiles_y;
+    uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x): tile / tiles_x == mul_hi(tile, inv_tiles_x) (set by the launcher)
 };
 
 // ---------------------------------------------------------------------------
@@ -103,6 +104,7 @@ struct PostArgs {
     uint32_t strength;           // 0 = no deblocking
     uint32_t tiles_x, tiles_y;
     uint32_t luma_only;          // standalone deblock() of a single plane
+    uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x) (set by the launcher)
 };
 
 // ---------------------------------------------------------------------------

@@ -9,6 +9,9 @@
 
 namespace h263mi {
 
+// n / d for a wave-uniform n with n * d < 2^32, r = ceil(2^32 / d) made by the launcher (d = 1 has no such r)
+__device__ __forceinline__ uint32_t div_tiles_x(uint32_t n, uint32_t d, uint32_t r) { return d == 1 ? n : __umulhi(n, r); }
+
 #if defined(H263MI_PROFILE_PHASES)
 // diagnosis build: wall-clock cycles (s_memtime) a wave spends in each phase of k_recon, summed over waves
 __device__ unsigned long long g_phase_cycles[8];
@@ -40,21 +43,22 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
     ReconWave &s = waves[wave];
-    // work list = (picture, tile, macroblock row of the tile[, half]); a workgroup takes RECON_WAVES consecutive
-    // entries.  With RECON_HALVES == 2 a wave does both halves of its macroblock row one after the other: the
-    // records are fetched (and waited for) once, and the second half finds its reference rows in L1.
-    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES;
-    const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * a.n_pictures * (kUnitsPerTile / RECON_WAVES);
-    const uint32_t chunk = (total + 7) / 8, xcd = blockIdx.x & 7;
+    // grid.y = picture; grid.x walks the picture's (tile, macroblock row[, half]) list, RECON_WAVES entries per
+    // workgroup, in XCD-aware order (gridDim.x is a multiple of 8, so blockIdx.x & 7 names the XCD for every
+    // picture).  With RECON_HALVES == 2 a wave does both halves of its macroblock row one after the other.
+    // No integer division on the device: the only one left, by tiles_x, is a multiply-high with a host-made reciprocal.
+    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES / RECON_WAVES;
+    const uint32_t upp = a.tiles_x * a.tiles_y * kUnitsPerTile;           // work items of one picture
+    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
     const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
-    if (t >= chunk || g >= total) return;
-    const uint32_t tile_g = g / (kUnitsPerTile / RECON_WAVES);
-    const int tw = ((int)(g % (kUnitsPerTile / RECON_WAVES)) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
-    const int tile = (int)(tile_g % tpp);
+    if (t >= chunk || g >= upp) return;
+    const uint32_t tile = g / kUnitsPerTile;                               // power of two
+    const int tw = ((int)(g % kUnitsPerTile) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
+    const uint32_t tile_y = div_tiles_x(tile, a.tiles_x, a.inv_tiles_x), tile_x = tile - tile_y * a.tiles_x;
     WavePos p;
-    p.pic = (int)(tile_g / tpp);
-    p.mbx0 = (tile % (int)a.tiles_x) * TILE_MBX;
-    p.mby = (tile / (int)a.tiles_x) * TILE_MBY + (tw >> 1);
+    p.pic = (int)blockIdx.y;
+    p.mbx0 = (int)tile_x * TILE_MBX;
+    p.mby = (int)tile_y * TILE_MBY + (tw >> 1);
     p.half = tw & 1;
     if (p.mby >= (int)a.L.mbh) return;
     p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
@@ -103,11 +107,18 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     }
 }
 
+// ceil(2^32 / d): n / d == mul_hi(n, r) for n * d < 2^32
+static uint32_t reciprocal_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
 {
-    const uint32_t total = args.tiles_x * args.tiles_y * args.n_pictures * (TILE_WAVES / RECON_HALVES / RECON_WAVES);
-    const uint32_t chunk = (total + 7) / 8;
-    hipLaunchKernelGGL(k_recon, dim3(chunk * 8), dim3(RECON_THREADS), 0, stream, args);
+    if (!args.n_pictures) return hipSuccess;
+    if (args.n_pictures > 65535 || args.tiles_x * args.tiles_y >= (1u << 20)) return hipErrorInvalidValue;
+    ReconArgs a = args;
+    a.inv_tiles_x = reciprocal_u32(args.tiles_x);
+    const uint32_t upp = args.tiles_x * args.tiles_y * (TILE_WAVES / RECON_HALVES / RECON_WAVES);
+    const uint32_t chunk = (upp + 7) / 8;
+    hipLaunchKernelGGL(k_recon, dim3(chunk * 8, args.n_pictures), dim3(RECON_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -159,15 +170,19 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     // cache lines the 4-pixel tile offset straddles -- are thus in different workgroups, start at slightly
     // different times, and the second one finds the shared lines in L2 (4 lock-stepped waves of one
     // workgroup missing on the same line at the same moment fetched it twice: +50 % FETCH_SIZE).
+    // grid.y = picture; grid.x walks the picture's list of (column sx, group of POST_GROUP vertical tiles, tile of the
+    // group) in XCD-aware order; divisions by tiles_x are multiply-highs with a host-made reciprocal
     const uint32_t groups_y = (a.tiles_y + POST_GROUP - 1) / POST_GROUP;
-    const uint32_t wpp = a.tiles_x * groups_y, units = wpp * a.n_pictures * (POST_GROUP / POST_WAVES);
-    const uint32_t chunk = (units + 7) / 8, xcd = blockIdx.x & 7;
+    constexpr uint32_t kUnitsPerGroup = POST_GROUP / POST_WAVES;
+    const uint32_t upp = a.tiles_x * groups_y * kUnitsPerGroup;
+    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
     const uint32_t t = blockIdx.x >> 3, unit = xcd * chunk + t;
-    if (t >= chunk || unit >= units) return;
-    const uint32_t wg = unit / (POST_GROUP / POST_WAVES);
-    const int gw = (int)(unit % (POST_GROUP / POST_WAVES)) * POST_WAVES + wave;       // tile of the group, 0..3
-    const int pic = (int)(wg / wpp), rem = (int)(wg % wpp);
-    const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_GROUP + gw;
+    if (t >= chunk || unit >= upp) return;
+    const uint32_t wg = unit / kUnitsPerGroup;
+    const int gw = (int)(unit % kUnitsPerGroup) * POST_WAVES + wave;       // tile of the group, 0..3
+    const int pic = (int)blockIdx.y;
+    const uint32_t gy = div_tiles_x(wg, a.tiles_x, a.inv_tiles_x);
+    const int sx = (int)(wg - gy * a.tiles_x), ty = (int)gy * POST_GROUP + gw;
     if (ty >= (int)a.tiles_y) return;
     const int sy0 = ty * POST_STRIPS;
     // no workgroup barrier anywhere: the wave owns its strips from load to store.  All loads of the
@@ -184,9 +199,13 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 
 hipError_t launch_post(const PostArgs &args, hipStream_t stream)
 {
+    if (!args.n_pictures) return hipSuccess;
+    if (args.n_pictures > 65535 || args.tiles_x * args.tiles_y >= (1u << 20)) return hipErrorInvalidValue;
+    PostArgs a = args;
+    a.inv_tiles_x = reciprocal_u32(args.tiles_x);
     const uint32_t groups_y = (args.tiles_y + POST_GROUP - 1) / POST_GROUP;
-    const uint32_t units = args.tiles_x * groups_y * args.n_pictures * (POST_GROUP / POST_WAVES), chunk = (units + 7) / 8;
-    hipLaunchKernelGGL(k_post, dim3(chunk * 8), dim3(POST_THREADS), 0, stream, args);
+    const uint32_t upp = args.tiles_x * groups_y * (POST_GROUP / POST_WAVES), chunk = (upp + 7) / 8;
+    hipLaunchKernelGGL(k_post, dim3(chunk * 8, args.n_pictures), dim3(POST_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -74,18 +74,21 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 #pragma unroll 1
     for (int h = 0; h < RECON_HALVES; h++, p.half++) {
         asm volatile("" : "+v"(ln));
-        recon_phase_mark(a, s, ln, p);
-        recon_phase_compact(a, s, ln);
+        WaveMasks km;
+        km.valid = recon_valid_mask(a, p);
+        km.act = km.inter = 0;
+        recon_phase_mark(a, s, ln, p, km);
+        recon_phase_compact(a, s, ln, km);
         PHASE_MARK(1);
         WaveFetch f;
-        recon_phase_fetch(a, s, f, ln, p);          // every global load of this half is in flight from here
-        const int n_active = recon_n_active(s);
+        recon_phase_fetch(a, s, f, ln, p, km);      // every global load of this half is in flight from here
+        const int n_active = recon_n_active(km);
         PHASE_MARK(2);
 #pragma unroll 1
         for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
             asm volatile("" : "+v"(ln));
             RowIn ri;
-            recon_phase_idct_load(a, s, f, ln, p, round, ri);
+            recon_phase_idct_load(a, s, f, ln, p, round, ri, km);
             // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
             const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
                                 (__ballot(ri.w[3] != 0) ? 8u : 0u);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
             rows_mask |= rows_mask >> 16;
             rows_mask |= rows_mask >> 8;
             asm volatile("" : "+v"(ln));
-            recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu));
+            recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu), km);
         }
         PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
 #if defined(H263MI_PROFILE_PHASES)
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
         PHASE_MARK(4);                              // reference rows have arrived
 #endif
         asm volatile("" : "+v"(ln));
-        recon_phase_output(a, s, f, ln, p);
+        recon_phase_output(a, s, f, ln, p, km);
         PHASE_MARK(5);
     }
 }

@@ -58,13 +58,18 @@ constexpr int RES_STRIDE = 192;                // residual strip row: 128 luma +
 struct ReconWave {
     MbRecord rec[TILE_MBX];                    // 256 B
     int16_t  mvc[TILE_MBX][2];                 // chroma vector per macroblock (gather.rs:182)
-    uint32_t valid_mask;                       // bit m: macroblock m lies inside the picture
-    uint32_t act_mask;                         // bit t: block task t goes through the IDCT
-    uint32_t inter_mask;                       // bit m: macroblock m is inside the picture and inter coded
     uint8_t  list[WAVE_TASKS];                 // compacted active tasks
     float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results; column 8 of each row keeps C[r][0] for the Vert class
     uint8_t  flags[ROUND_BLOCKS * 8];
     int16_t  res[8 * RES_STRIDE];              // residual strip: 8 rows x (128 luma | 64 chroma) columns
+};
+
+// Wave-wide bit masks.  On the device they come out of ballots and live in scalar registers; the CPU logic checker
+// (tests/sim) runs the lanes one after the other and ORs the lanes' bits together.
+struct WaveMasks {
+    uint32_t valid;            // bit m: macroblock m lies inside the picture
+    uint32_t act;              // bit t: block task t goes through the IDCT
+    uint32_t inter;            // bit m: macroblock m is inside the picture and inter coded
 };
 
 // position of a wave's work: which picture, which row of macroblocks, which half
@@ -278,6 +283,12 @@ H263_DEV float dequant_f32(float level, float two_q, float q_minus_parity)
 }
 
 // ---- phase 0: records -> LDS -------------------------------------------------------
+H263_DEV uint32_t recon_valid_mask(const ReconArgs &a, const WavePos &p)
+{
+    const int n = (int)a.L.mbw - p.mbx0;                        // macroblocks of the tile inside the picture
+    return (p.mby < (int)a.L.mbh && n > 0) ? (n >= TILE_MBX ? 0xffu : (1u << n) - 1u) : 0u;
+}
+
 H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p)
 {
     if (lane < TILE_MBX * 2) {
@@ -291,67 +302,61 @@ H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const
         }
         reinterpret_cast<uint4 *>(&s.rec[m])[part] = v;
     }
-    if (lane == 16) {
-        uint32_t vm = 0;
-        for (int m = 0; m < TILE_MBX; m++)
-            if (p.mbx0 + m < (int)a.L.mbw && p.mby < (int)a.L.mbh) vm |= 1u << m;
-        s.valid_mask = vm;
-        s.act_mask = 0;
-        s.inter_mask = 0;
-    }
 }
 
 // ---- phase 1: which blocks need the IDCT; chroma vectors -------------------------------
-H263_DEV void recon_phase_mark(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p)
+// Straight-line: every lane reads the record words it might need in one go (one wait), the decisions are
+// plain arithmetic, and the two masks are ballots over the whole wave.  `k` masks must arrive with valid set and
+// act = inter = 0.
+H263_DEV void recon_phase_mark(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, WaveMasks &k)
 {
-    if (lane < WAVE_TASKS) {
-        const int m = task_mb(lane), blk = task_blk(lane, p.half);
-        const MbRecord &r = s.rec[m];
-        const bool valid = (s.valid_mask >> m) & 1;
-        const bool coded = (r.cbp >> blk) & 1;
-        const bool kill = (r.kill >> blk) & 1;
-        const bool intra = mb_is_intra(r.mb_type);
-        // coded & kill -> Zero (rle.rs:125-127); uncoded inter -> Zero; uncoded intra -> Dc(level)
-        const bool active = valid && ((coded && !kill) || (!coded && intra && intradc_level(r.intradc[blk]) != 0));
+    // lanes 0..23: block task `lane`; lanes 24..31: macroblock lane - 24 (chroma vector, inter flag)
+    const bool is_task = lane < WAVE_TASKS, is_mb = lane >= WAVE_TASKS && lane < WAVE_TASKS + TILE_MBX;
+    const int m = is_task ? task_mb(lane) : ((lane - WAVE_TASKS) & (TILE_MBX - 1));
+    const int blk = is_task ? task_blk(lane, p.half) : 0;
+    const MbRecord &r = s.rec[m];
+    uint32_t head;                                               // mb_type | quant << 8 | cbp << 16 | kill << 24
+    memcpy(&head, &r, 4);
+    const uint32_t dc = r.intradc[blk];
+    uint32_t mv[4];
+    memcpy(mv, &r.mv[0][0], 16);
+    const uint32_t mb_type = head & 0xffu, cbp = (head >> 16) & 0xffu, kill = head >> 24;
+    const bool valid = (k.valid >> m) & 1;
+    const bool coded = (cbp >> blk) & 1;
+    // coded & kill -> Zero (rle.rs:125-127); uncoded inter -> Zero; uncoded intra -> Dc(level)
+    const bool active = is_task && valid &&
+                        (coded ? !((kill >> blk) & 1) : (mb_is_intra(mb_type) && intradc_level(dc) != 0));
+    // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
+    const bool inter = is_mb && valid && mb_is_inter(mb_type);
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t mask = (uint32_t)__ballot(active);        // lanes 0..23 are the only ones here
-        if (lane == 0) s.act_mask = mask;
+    k.act = (uint32_t)__ballot(active);
+    k.inter = (uint32_t)(__ballot(inter) >> WAVE_TASKS) & 0xffu;
+    if (k.inter && !a.has_ref && lane == 0) atomicOr(a.status, STATUS_INTER_WITHOUT_REFERENCE);   // Error::UncodedIFrameBlocks
 #else
-        if (active) s.act_mask |= 1u << lane;
+    if (active) k.act |= 1u << lane;
+    if (inter) {
+        k.inter |= 1u << m;
+        if (!a.has_ref) *a.status |= STATUS_INTER_WITHOUT_REFERENCE;
+    }
 #endif
-    } else if (lane < WAVE_TASKS + TILE_MBX) {
+    if (is_mb) {
         // gather.rs:182: chroma vector from the i16 sum of the four luma vectors
-        const int m = lane - WAVE_TASKS;
-        const MbRecord &r = s.rec[m];
-        s.mvc[m][0] = (int16_t)average_sum_of_mvs(r.mv[0][0] + r.mv[1][0] + r.mv[2][0] + r.mv[3][0]);
-        s.mvc[m][1] = (int16_t)average_sum_of_mvs(r.mv[0][1] + r.mv[1][1] + r.mv[2][1] + r.mv[3][1]);
-        // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
-        const bool inter = ((s.valid_mask >> m) & 1) && mb_is_inter(r.mb_type);
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t im = (uint32_t)(__ballot(inter) >> WAVE_TASKS);      // lanes 24..31 are the only ones here
-        if (m == 0) {
-            s.inter_mask = im;
-            if (im && !a.has_ref) atomicOr(a.status, STATUS_INTER_WITHOUT_REFERENCE);   // Error::UncodedIFrameBlocks
-        }
-#else
-        if (inter) {
-            s.inter_mask |= 1u << m;
-            if (!a.has_ref) *a.status |= STATUS_INTER_WITHOUT_REFERENCE;
-        }
-#endif
+        const int sx = (int16_t)(mv[0] & 0xffffu) + (int16_t)(mv[1] & 0xffffu) + (int16_t)(mv[2] & 0xffffu) + (int16_t)(mv[3] & 0xffffu);
+        const int sy = (int16_t)(mv[0] >> 16) + (int16_t)(mv[1] >> 16) + (int16_t)(mv[2] >> 16) + (int16_t)(mv[3] >> 16);
+        s.mvc[m][0] = (int16_t)average_sum_of_mvs(sx);
+        s.mvc[m][1] = (int16_t)average_sum_of_mvs(sy);
     }
 }
 
 // ---- phase 2: compact the active tasks ----------------------------------------------
-H263_DEV void recon_phase_compact(const ReconArgs &, ReconWave &s, int lane)
+H263_DEV void recon_phase_compact(const ReconArgs &, ReconWave &s, int lane, const WaveMasks &k)
 {
     if (lane >= WAVE_TASKS) return;
-    const uint32_t mw = s.act_mask;
-    if (!((mw >> lane) & 1)) return;
-    s.list[popc32(mw & ((1u << lane) - 1u))] = (uint8_t)lane;
+    if (!((k.act >> lane) & 1)) return;
+    s.list[popc32(k.act & ((1u << lane) - 1u))] = (uint8_t)lane;
 }
 
-H263_DEV int recon_n_active(const ReconWave &s) { return popc32(s.act_mask); }
+H263_DEV int recon_n_active(const WaveMasks &k) { return popc32(k.act); }
 
 // ---- phase 3: issue every global load of the wave ------------------------------------------
 // One 8-pixel row segment of the lane: its motion vector and the raw reference bytes (12 per
@@ -459,13 +464,13 @@ H263_DEV void gather_row_clamped(uint32_t w[3], int u, int ub, int pw)
 // compensation reads.  A lane whose macroblock takes no prediction behaves like a zero vector (its
 // bytes are dropped in the output phase); lanes whose taps leave the picture are fixed up there too.
 // Every address is a wave-uniform plane base plus a 32-bit lane offset.
-H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, int lane, const WavePos &p)
+H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
 {
     const uint8_t *ref = a.ref + (size_t)p.pic * a.L.frame_bytes;
     {
         const uint8_t *src = reinterpret_cast<const uint8_t *>(a.mbs);      // dummy: any mapped address
         const int slot = lane >> 3, r = lane & 7;
-        if (slot < recon_n_active(s)) {
+        if (slot < recon_n_active(km)) {
             const int t = s.list[slot];
             const int m = task_mb(t), blk = task_blk(t, p.half);
             const MbRecord &rec = s.rec[m];
@@ -480,7 +485,7 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
     }
     // gather.rs:149: without a reference picture nothing is motion compensated (the error is already
     // in the status word)
-    const uint32_t mc_mask = a.has_ref ? wave_uniform(s.inter_mask) : 0u;
+    const uint32_t mc_mask = a.has_ref ? km.inter : 0u;
     f.flags = 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -528,13 +533,13 @@ struct RowIn {
 };
 
 H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
-                                    int round, RowIn &ri)
+                                    int round, RowIn &ri, const WaveMasks &km)
 {
     ri.w[0] = ri.w[1] = ri.w[2] = ri.w[3] = 0;
     ri.quant = 1; ri.dc_level = 0; ri.active = 0; ri.use_dc = 0;
     const int slot = lane >> 3, r = lane & 7;
     const int k = round * ROUND_BLOCKS + slot;
-    if (k >= recon_n_active(s)) return;
+    if (k >= recon_n_active(km)) return;
     const int t = s.list[k];
     const int m = task_mb(t), blk = task_blk(t, p.half);
     const MbRecord &rec = s.rec[m];
@@ -610,11 +615,11 @@ H263_DEV bool recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
 }
 
 // ---- phase 4b: column pass, rounding, residual strip -------------------------------------
-H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, int round, int n_rows)
+H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, int round, int n_rows, const WaveMasks &km)
 {
     const int slot = lane >> 3, i = lane & 7;
     const int k = round * ROUND_BLOCKS + slot;
-    if (k >= recon_n_active(s)) return;
+    if (k >= recon_n_active(km)) return;
     const int t = s.list[k];
 
     uint64_t fl;
@@ -658,10 +663,10 @@ H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, i
 }
 
 // ---- phase 5: interpolation + residual + clip + store ------------------------------------
-H263_DEV void recon_phase_output(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p)
+H263_DEV void recon_phase_output(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
 {
     uint8_t *cur = a.cur + (size_t)p.pic * a.L.frame_bytes;
-    const uint32_t valid_mask = wave_uniform(s.valid_mask), act_mask = wave_uniform(s.act_mask);
+    const uint32_t valid_mask = km.valid, act_mask = km.act;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const SegGeo g = seg_geometry(a, lane, k, p);

@@ -54,21 +54,24 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
             p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;
             memset(s, 0xA5, sizeof *s);   // LDS is not zero-initialised on the device either
             for (int l = 0; l < 64; l++) recon_phase_load(a, *s, l, p);
-            for (int l = 0; l < 64; l++) recon_phase_mark(a, *s, l, p);
-            for (int l = 0; l < 64; l++) recon_phase_compact(a, *s, l);
-            for (int l = 0; l < 64; l++) recon_phase_fetch(a, *s, f[l], l, p);
-            const int n_active = recon_n_active(*s);
+            WaveMasks km;
+            km.valid = recon_valid_mask(a, p);
+            km.act = km.inter = 0;
+            for (int l = 0; l < 64; l++) recon_phase_mark(a, *s, l, p, km);        // the lanes OR their bits into km
+            for (int l = 0; l < 64; l++) recon_phase_compact(a, *s, l, km);
+            for (int l = 0; l < 64; l++) recon_phase_fetch(a, *s, f[l], l, p, km);
+            const int n_active = recon_n_active(km);
             for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
                 static RowIn ri[64];
                 uint32_t wm = 0, rm = 0;
                 for (int l = 0; l < 64; l++) {
-                    recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l]);
+                    recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l], km);
                     wm |= rowin_word_mask(ri[l]);          // the device kernel does these two reductions with ballots
                 }
                 for (int l = 0; l < 64; l++) rm |= recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm)) ? 1u << (l & 7) : 0u;
-                for (int l = 0; l < 64; l++) recon_phase_idct_cols(a, *s, l, round, rows_from_mask(rm));
+                for (int l = 0; l < 64; l++) recon_phase_idct_cols(a, *s, l, round, rows_from_mask(rm), km);
             }
-            for (int l = 0; l < 64; l++) recon_phase_output(a, *s, f[l], l, p);
+            for (int l = 0; l < 64; l++) recon_phase_output(a, *s, f[l], l, p, km);
         }
     }
     free(s);

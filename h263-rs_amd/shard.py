@@ -28,6 +28,11 @@ def barrier(dist, sync_device=None):
 def timed_region(dist, run, sync_device=None):
     """barrier + device sync | run() | device sync + barrier; returns the MAX elapsed seconds over ranks."""
     import torch
+    if dist is not None and dist.is_initialized():
+        # the closing barrier is inside the timed region: make sure it is a warm one (the first RCCL barriers of a
+        # process set up communicators and cost about a millisecond)
+        for _ in range(3):
+            dist.barrier()
     barrier(dist, sync_device)
     t0 = time.perf_counter()
     run()

@@ -499,3 +499,43 @@ def test_batch_overlap_mode_gives_the_same_pictures():
     for s in range(n):
         assert_planes_equal(b.copy_yuv(s), refs[s], "stream %d" % s)
     b.close()
+
+
+def test_states_on_different_host_threads():
+    """include/h263mi.h: one h263mi_state per stream, not thread-safe per object, but distinct states may be driven
+    from different host threads (ctypes releases the GIL inside the calls)."""
+    import threading
+    w, h, n_threads, n_frames = 176, 144, 6, 6
+    errors = []
+
+    def worker(tid):
+        try:
+            st = h263mi.H263State()
+            ref = None
+            for f in range(n_frames):
+                if f == 0:
+                    mbs, co = recgen.intra_picture(w, h, seed=100 + tid)
+                    pt = h263mi.PICTURE_I
+                else:
+                    mbs, co = recgen.inter_picture(w, h, seed=1000 * tid + f, mv_range=40, p_4v=0.3, p_coded=0.4, quant=5 + tid)
+                    pt = h263mi.PICTURE_P
+                st.submit_picture(w, h, mbs, co, pt, temporal_reference=f)
+                rc, ref = orc.decode_picture(w, h, mbs, co, ref if f else None)
+                got = st.get_last_picture().as_yuv()
+                for g, e in zip(got, ref):
+                    if not (np.asarray(g) == e).all():
+                        errors.append((tid, f))
+                cw = (w + 1) // 2
+                planes = tuple(orc.deblock(p, pw, 4) for p, pw in zip(ref, (w, cw, cw)))
+                if not (st.render_rgba(4) == orc.yuv420_to_rgba(*planes, w)).all():
+                    errors.append((tid, f, "rgba"))
+            st.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -273,13 +273,32 @@ H263_DEV float clampf(float v, float lo, float hi)
 #endif
 }
 
-// rle.rs:130-133 on a float copy of the LEVEL (all values are small integers, exact in f32):
-// sign(L) * (q*(2|L|+1) - (q even)) = L*2q + sign(L)*(q - parity), clamped to [-2048, 2047]; 0 stays 0
-H263_DEV float dequant_f32(float level, float two_q, float q_minus_parity)
+// rle.rs:130-133 for two LEVELs at once, as they arrive (a pair of int16 in one dword):
+// sign(L) * (q*(2|L|+1) - (q even)) = L*2q + sign(L)*(q - parity), clamped to [-2048, 2047]; 0 stays 0.
+// Packed 16-bit integer arithmetic; the multiply-add saturates to the i16 range (the reference's i16 product would
+// overflow for 11-bit LEVELs at large quantisers; a saturated value lands on the same side of the final clamp).
+// `two_q2`, `qmp2`: 2q and q - parity in both halves of a dword.
+H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qmp2)
 {
-    const float sg = clampf(level, -1.0f, 1.0f);                            // -1, 0 or +1
-    const float v = level * two_q + sg * q_minus_parity;                    // exact: integers below 2^24
-    return clampf(v, -2048.0f, 2047.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // all in inline asm: written with vector min/max the compiler turns the sign into four compares and selects
+    uint32_t sg, t, v;
+    asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]" : "=&v"(sg) : "v"(levels));   // -1, 0 or +1
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2));
+    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
+    asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_i16 %0, %0, %3" : "=&v"(t) : "v"(v), "v"(0xf800f800u), "v"(0x07ff07ffu));
+    return t;
+#else
+    uint32_t out = 0;
+    for (int h = 0; h < 2; h++) {
+        const int level = (int)(int16_t)(levels >> (16 * h));
+        const int two_q = (int)(two_q2 & 0xffffu), qmp = (int)(int16_t)(qmp2 & 0xffffu);
+        const int sg = level > 0 ? 1 : (level < 0 ? -1 : 0);
+        const int v = clampi(level * two_q + sg * qmp, -2048, 2047);
+        out |= ((uint32_t)v & 0xffffu) << (16 * h);
+    }
+    return out;
+#endif
 }
 
 // ---- phase 0: records -> LDS -------------------------------------------------------
@@ -581,16 +600,17 @@ H263_DEV bool recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
 {
     if (!ri.active) return false;
     const int slot = lane >> 3, r = lane & 7;
-    const int quant = ri.quant;
-    const float two_q = (float)(2 * quant), qmp = (float)(quant - ((quant & 1) ? 0 : 1));
+    const uint32_t quant = (uint32_t)ri.quant;
+    const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = (quant - ((quant & 1u) ? 0u : 1u)) * 0x00010001u;
 
     float C[8];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         C[2 * j] = C[2 * j + 1] = 0.0f;
         if (2 * j < n_cols) {                               // uniform
-            C[2 * j] = dequant_f32((float)(int)(int16_t)(ri.w[j] & 0xffffu), two_q, qmp);
-            C[2 * j + 1] = dequant_f32((float)((int)ri.w[j] >> 16), two_q, qmp);
+            const uint32_t v = dequant_pair_i16(ri.w[j], two_q2, qmp2);
+            C[2 * j] = (float)(int)(int16_t)(v & 0xffffu);
+            C[2 * j + 1] = (float)((int)v >> 16);
         }
     }
     if (ri.use_dc) C[0] = (float)ri.dc_level;

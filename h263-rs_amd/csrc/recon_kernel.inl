@@ -22,7 +22,7 @@
 //              the lane's three segments (one dword-aligned 12-byte load per row; rows nobody
 //              needs read offset 0; picture-edge segments load the window that holds all their
 //              clamped taps) and the coefficient row of the first IDCT round
-//   idct     : rounds of 8 blocks, 8 lanes per block, lane = one coefficient row: dequant,
+//   idct     : rounds of 8 blocks, 8 lanes per block, lane = one coefficient row: dequant (packed i16),
 //              row pass T = C x B -> LDS; then lane = one pixel column: column of T (the
 //              LDS transposition), column pass, rounding -> residual strip (i16) in LDS; both
 //              passes stop at the last non-zero coefficient column / row of the round

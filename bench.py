@@ -1,37 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- decoded megapixels/s of the MI355X macroblock back-end (BASELINE.json metric).
 
-Workload (config.workload): BASELINE configs[3] -- a batch of 64 independent 1080p streams on
-each GPU.  A step is one frame index over the whole batch: k_recon (dequant + IDCT + half-pel
-MC + residual add/clip) and k_post (deblock strength 5 + BT.601 -> RGBA) for 64 pictures.
-Frames cycle through a GOP of 31: one I picture (mixed block classes) then 30 P pictures
-(half-pel vectors in [-32, 31], 25 % coded blocks, quant 10).  Records are generated on the
-device beforehand (counter-based splitmix64), so inputs are resident in HBM when
-the timed region starts.  With --gpus N every rank decodes its own 64 streams (weak scaling,
-no data-path collective); RCCL only carries the barrier and the max-over-ranks reduction.
+Workload (config.workload): BASELINE configs[3] -- a batch of 64 independent 1080p streams on each GPU.
+A STEP is one pass over the resident synthetic input of the batch: GOPS_PER_STEP GOPs of 31 frame indices (1 I
+picture with mixed block classes, then 30 P pictures: half-pel vectors in [-32, 31], 25 % coded blocks, quant 10)
+for all 64 streams, i.e. 64 x 124 pictures per step.  Per frame index: k_recon (dequant + IDCT + half-pel MC +
+residual add/clip) and k_post (deblock strength 5 + BT.601 -> RGBA) over the 64 pictures.  Records are generated on
+the device beforehand (counter-based splitmix64), so inputs are resident in HBM when the timed region
+starts.  With --gpus N every rank decodes its own 64 streams (weak scaling, no data-path collective); RCCL only
+carries the barrier and the max-over-ranks reduction.  `python bench.py --gpus N` launches the N ranks itself
+(torch.distributed.run); under an external launcher (WORLD_SIZE set) it is one of the ranks.
 
-One JSON line is printed by rank 0.  `roofline` is for the kernel with the larger share of the
-timed region; `cpu_baseline` is the C oracle (a port of the reference CPU path, not the Rust
-binary) timed on this box's host cores.
+After the timed region, and outside it, a PARITY GATE downloads the last picture (Y, Cb, Cr and RGBA) of streams
+0, 31 and 63 of the 64-stream batch and compares it with the CPU oracle run from the GOP's I picture; a mismatch
+makes the run fail.
+
+One JSON line is printed by rank 0.  `roofline` is for the kernel with the larger share of the timed region;
+`cpu_baseline` is the C oracle (a port of the reference CPU path, not the Rust binary) built natively on this box
+(-O3 -march=native -ffp-contract=off) and timed on its host cores with one stream per thread.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
-
-import torch  # first: torch brings its own HIP runtime; the C-ABI library must share it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "h263-rs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-
-import h263mi  # noqa: E402
-import shard  # noqa: E402
 
 W, H = 1920, 1080
 MBS_PP = 120 * 68
@@ -40,15 +40,73 @@ Y_BYTES, C_BYTES = W * H, 960 * 540
 YUV_BYTES = Y_BYTES + 2 * C_BYTES            # 3 110 400
 RGBA_BYTES = W * H * 4                       # 8 294 400
 HDR_BYTES = MBS_PP * 32                      # 261 120
-HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
 STRENGTH = 5                                 # QUANT_TO_STRENGTH[10] (deblock.rs:5-8)
+GOP = 31
+GOPS_PER_STEP = 4                            # 124 frame indices per step: >= 0.5 s of device time in 12+ steps
+PARITY_STREAMS = (0, 31, 63)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--gop", type=int, default=GOP)
+    ap.add_argument("--gops-per-step", type=int, default=GOPS_PER_STEP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="profiling runs only: the line then says so")
+    ap.add_argument("--overlap", action="store_true",
+                    help="k_post on a second stream (post of picture i beside recon of picture i+1); measured: no gain")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N-rank launch: one process per GPU.  Runs BEFORE anything touches the GPU (a process that has initialised HIP
+# must never be replaced or forked into ranks).
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    """Devices visible to this process, WITHOUT initialising the runtime (torch.cuda.device_count() does not, on
+    this image).  H263MI_BENCH_STUB: CPU stand-in workload over gloo (tests/test_bench_launcher.py), any N."""
+    if os.environ.get("H263MI_BENCH_STUB"):
+        return 1 << 10
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher around it: start N ranks of this file and return their exit code."""
+    have = visible_gpus()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible; refusing to report a smaller job as "
+                         "n_gpus=%d\n" % (args.gpus, have, args.gpus))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------------------
 class Workload:
     """Device-resident records of `gop` frame indices for `n` streams."""
 
-    def __init__(self, n, gop, first_stream, device_id, stream, i_kind=h263mi.SYNTH_I_MIXED, p_frames=True):
-        self.n, self.frames = n, []
+    def __init__(self, h263mi, n, gop, first_stream, device_id, stream, i_kind=None, p_frames=True):
+        i_kind = h263mi.SYNTH_I_MIXED if i_kind is None else i_kind
+        self.n, self.frames, self.h263mi = n, [], h263mi
         for f in range(gop):
             kind = i_kind if (f == 0 or not p_frames) else h263mi.SYNTH_P
             cap = n * MBS_PP * (6 if kind != h263mi.SYNTH_P else 2)
@@ -65,119 +123,204 @@ class Workload:
         (P only) + reconstructed planes written."""
         fr = self.frames[f]
         b = self.n * HDR_BYTES + fr["blocks"] * 128 + self.n * YUV_BYTES
-        if fr["ptype"] == h263mi.PICTURE_P:
+        if fr["ptype"] == self.h263mi.PICTURE_P:
             b += self.n * YUV_BYTES
         return b
 
     def post_bytes(self):
-        """algorithmic bytes of one k_post launch: the RGBA frames written.  Re-reading the
-        reconstructed planes is the price of running deblock + convert as a second kernel and is
-        NOT counted (a fully fused pipeline would keep them on chip)."""
+        """algorithmic bytes of one k_post launch: the RGBA frames written.  Re-reading the reconstructed planes is
+        the price of running deblock + convert as a second kernel and is NOT counted (a fully fused pipeline would
+        keep them on chip)."""
         return self.n * RGBA_BYTES
 
 
-def run_steps(batch, wl, d_rgba, first, count):
+def run_frames(batch, wl, d_rgba, n_frames):
+    """n_frames frame indices starting at a GOP boundary (every GOP re-starts all streams with an I picture)."""
     g = len(wl.frames)
-    for i in range(first, first + count):
+    for i in range(n_frames):
         fr = wl.frames[i % g]
         batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
         batch.render_rgba(STRENGTH, d_rgba.ptr, None)
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle (C restatement of the reference CPU path) on the host cores of this box: the same
-    synthetic 1080p stream (I + P pictures, deblock strength 5 on the three planes, BT.601), one
-    independent stream per thread like the reference's single-threaded-per-stream design."""
-    from oracle import oracle as orc   # checker/baseline only: never on the product path
-
-    def decode_stream(stream_id, n_frames, out):
-        ref, px = None, 0
-        for f in range(n_frames):
+def parity_gate(h263mi, batch, d_rgba, first_stream, n, gop, streams=PARITY_STREAMS):
+    """BASELINE.md section 3 "parity gate": the batch has just decoded whole GOPs; its last picture (frame index
+    gop-1, after gop-1 chained P pictures) of a few streams must equal the oracle's, planes and RGBA, bit for bit.
+    The oracle is the checker here -- it is never on the timed or shipped path."""
+    import numpy as np
+    from oracle import oracle as orc
+    checked = []
+    for s in streams:
+        if s >= n:
+            continue
+        ref = None
+        for f in range(gop):
             kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
-            mbs, co = h263mi.synth_picture_host(kind, W, H, stream_id, f)
-            t0 = time.perf_counter()
+            mbs, co = h263mi.synth_picture_host(kind, W, H, first_stream + s, f)
             rc, ref = orc.decode_picture(W, H, mbs, co, ref)
-            assert rc == 0
-            filt = tuple(orc.deblock(p, pw, STRENGTH) for p, pw in zip(ref, (W, 960, 960)))
-            orc.yuv420_to_rgba(*filt, W)
-            out[0] += time.perf_counter() - t0
-            px += 1
-        out[1] = px
+            if rc != 0:
+                return "oracle error %d (stream %d frame %d)" % (rc, s, f), checked
+        got = batch.copy_yuv(s)
+        for name, g, e in zip(("Y", "Cb", "Cr"), got, ref):
+            if not np.array_equal(g, e):
+                return "stream %d: %s plane differs from the oracle in %d bytes" % (s, name, int((g != e).sum())), checked
+        filt = tuple(orc.deblock(p, pw, STRENGTH) for p, pw in zip(ref, (W, 960, 960)))
+        want = orc.yuv420_to_rgba(*filt, W)
+        rgba = d_rgba.download(RGBA_BYTES, s * RGBA_BYTES)
+        if not np.array_equal(rgba, want):
+            return "stream %d: RGBA differs from the oracle in %d bytes" % (s, int((rgba != want).sum())), checked
+        checked.append(first_stream + s)
+    return "ok", checked
 
-    orc.lib()
-    probe = [0.0, 0]
-    decode_stream(0, 3, probe)                       # 1 I + 2 P on one core
-    per_frame = probe[0] / probe[1]
-    one_thread = MP_PER_PICTURE / per_frame
-    cores = os.cpu_count() or 1
-    n_frames = int(max(3, min(31, budget_s / per_frame)))
-    outs = [[0.0, 0] for _ in range(cores)]
-    threads = [threading.Thread(target=decode_stream, args=(100 + i, n_frames, outs[i])) for i in range(cores)]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    wall = time.perf_counter() - t0
-    busy = max(o[0] for o in outs)                   # excludes the record generation
-    value = cores * n_frames * MP_PER_PICTURE / busy
+
+def kernel_source_hash():
+    """identifies the kernel code a committed PMC traffic figure belongs to"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "h263-rs_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".inl", ".hip", ".h")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle, built natively on this box, one stream per thread (pthreads inside the C library)
+# ---------------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """physical cores this process may use: lscpu's cores x sockets, capped by the affinity mask"""
+    model, cores = "unknown", None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = dict((k.strip(), v.strip()) for k, v in (ln.split(":", 1) for ln in txt.splitlines() if ":" in ln))
+        model = kv.get("Model name", model)
+        cores = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+    except Exception:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if not cores:
+        cores = max(1, avail // 2)
+    return max(1, min(cores, avail)), avail, model
+
+
+def cpu_baseline(h263mi, budget_s=12.0):
+    from oracle import native_bench       # checker/baseline only: never on the product path
+    t_build = time.perf_counter()
+    nb = native_bench.NativeOracle()      # gcc -O3 -march=native -ffp-contract=off, on this box
+    t_build = time.perf_counter() - t_build
+    cores, logical, model = physical_cores()
+    n_distinct = min(cores, 4)
+    streams = []
+    for s in range(n_distinct):
+        pics = []
+        for f in range(GOP):
+            kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
+            pics.append(h263mi.synth_picture_host(kind, W, H, 100 + s, f))
+        streams.append(pics)
+    nb.check_against_portable(W, H, streams[0][:3], STRENGTH)      # byte-equal to the -O2 oracle before timing
+    one = nb.run(W, H, streams[:1], 1, 1, STRENGTH)                # 1 thread, one GOP
+    one_mp = GOP * MP_PER_PICTURE / one
+    # T threads, one stream each, whole GOPs; bounded to ~budget_s of wall clock (memory-bound: assume up to 3x slower)
+    gops = max(1, min(8, int(budget_s / (3.0 * one))))
+    wall = nb.run(W, H, streams, cores, gops, STRENGTH)
+    value = cores * gops * GOP * MP_PER_PICTURE / wall
     return {"value": round(value, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x 1 stream x %d pictures (1 I + %d P) of the bench workload at 1920x1080, "
-                      "recon + deblock(5) x3 planes + BT.601; C oracle (port of the h263-rs CPU path, not the "
-                      "Rust binary); %.1f s wall" % (cores, n_frames, n_frames - 1, wall),
-            "one_thread_mp_s": round(one_thread, 2)}
+            "cores_physical": cores, "cpus_logical": logical, "cpu_model": model,
+            "flags": nb.flags, "one_thread_mp_s": round(one_mp, 2),
+            "parallel_efficiency": round(value / (cores * one_mp), 3),
+            "sample": "%d threads (one per physical core) x 1 stream x %d GOP(s) of 31 pictures (1 I + 30 P) of the bench "
+                      "workload at 1920x1080, recon + deblock(%d) x3 planes + BT.601; C oracle (port of the h263-rs CPU "
+                      "path, not the Rust binary) with pthreads, %d distinct streams shared read-only; %.1f s wall, "
+                      "built in %.1f s" % (cores, gops, STRENGTH, n_distinct, wall, t_build)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=62)
-    ap.add_argument("--warmup", type=int, default=31)
-    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
-    ap.add_argument("--gop", type=int, default=31)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="k_post on a second stream (post of picture i beside recon of picture i+1); measured: no gain, "
-                         "both kernels fill the chip")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------
+def stub_main(args, rank, world):
+    """CPU stand-in for the launcher test: same rendezvous, barrier and aggregation code over gloo, no GPU work."""
+    import torch.distributed as dist
+    import shard
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    else:
+        dist = None
+    elapsed = shard.timed_region(dist, lambda: time.sleep(0.01 * args.steps))
+    pictures = shard.aggregate_pictures(dist, args.streams * args.steps * args.gop * args.gops_per_step)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": pictures * MP_PER_PICTURE / elapsed, "unit": "MP/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "data": "stub (no GPU work)",
+                          "pictures": pictures}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)                 # first thing, before torch.cuda.* or any h263mi call
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if os.environ.get("H263MI_BENCH_STUB"):
+        return stub_main(args, rank, world)
+
+    import torch  # before h263mi: torch brings its own HIP runtime; the C-ABI library must share it
+    import h263mi
+    import shard
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X back-end has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: no device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("H263MI_FORCE_DIST"):      # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
     stream = torch.cuda.current_stream().cuda_stream
     n = args.streams
     my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU
-    wl = Workload(n, args.gop, my_streams[0], local_rank, stream)
+    wl = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream)
     batch = h263mi.Batch(n, W, H, local_rank, stream, overlap_post=args.overlap)
     d_rgba = h263mi.DeviceBuffer(n * RGBA_BYTES, local_rank)
+    frames_per_step = args.gop * args.gops_per_step
 
-    run_steps(batch, wl, d_rgba, 0, args.warmup)
+    batch.timing_reserve(2 * frames_per_step * max(args.steps, 1))   # no event is created inside the timed region
+    run_frames(batch, wl, d_rgba, frames_per_step * args.warmup)
     batch.sync()
     batch.timing_begin()
     # barrier + synchronize | exactly K steps | synchronize + barrier; MAX over ranks
-    elapsed = shard.timed_region(dist, lambda: run_steps(batch, wl, d_rgba, args.warmup, args.steps),
+    elapsed = shard.timed_region(dist, lambda: run_frames(batch, wl, d_rgba, frames_per_step * args.steps),
                                  torch.cuda.synchronize)
     kt = batch.timing_end()
     batch.sync()
 
-    pictures = shard.aggregate_pictures(dist, n * args.steps)
+    pictures = shard.aggregate_pictures(dist, n * frames_per_step * args.steps)
     value = pictures * MP_PER_PICTURE / elapsed
+
+    # ---- parity gate (outside the timed region): every rank checks its own streams; any failure fails the job
+    gate, gate_streams = ("skipped", [])
+    if not args.no_parity_gate:
+        gate, gate_streams = parity_gate(h263mi, batch, d_rgba, my_streams[0], n, args.gop)
+    gate_bad = 0 if gate in ("ok", "skipped") else 1
+    if dist is not None:
+        t = torch.tensor([gate_bad], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gate_bad = int(t.item())
+    if gate_bad and gate == "ok":
+        gate = "failed on another rank"
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region only)
     g = len(wl.frames)
-    recon_alg = sum(wl.recon_bytes(i % g) for i in range(args.warmup, args.warmup + args.steps)) / max(args.steps, 1)
+    recon_alg = sum(wl.recon_bytes(i % g) for i in range(frames_per_step)) / frames_per_step
+    recon_alg_p = wl.recon_bytes(1) if g > 1 else recon_alg
     post_alg = wl.post_bytes()
     recon_avg_ms = kt.recon_ms / max(kt.recon_launches, 1)
     post_avg_ms = kt.post_ms / max(kt.post_launches, 1)
@@ -188,36 +331,55 @@ def main():
     for k in kernels.values():
         k["achieved_gbs"] = k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
     dom = "k_post" if kt.post_ms >= kt.recon_ms else "k_recon"
-    # HBM traffic of that kernel from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
-    # collected by tools/prof_final.sh in separate rocprofv3 --pmc runs of this same workload; null if absent)
-    traffic = None
+
+    # on-box ceilings, measured in this run: plain copy / read / write kernels over 1 GiB
+    cfg_stream = stream
+    peak_copy = h263mi.probe_bandwidth(h263mi.PROBE_COPY, 1 << 30, 10, local_rank, cfg_stream)
+    peak_read = h263mi.probe_bandwidth(h263mi.PROBE_READ, 1 << 30, 10, local_rank, cfg_stream)
+    peak_write = h263mi.probe_bandwidth(h263mi.PROBE_WRITE, 1 << 30, 10, local_rank, cfg_stream)
+
+    # HBM traffic of that kernel: FETCH_SIZE + WRITE_SIZE from the separate rocprofv3 --pmc passes of
+    # tools/prof_final.sh, committed under profiles/.  It cannot be measured from inside this process, so it is
+    # reported only when the committed figure was taken on exactly this kernel source.
+    traffic, traffic_source = None, None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if n == 64 and world == 1:
+        if n == 64 and tr.get("kernel_source_hash") == kernel_source_hash():
             traffic = tr["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_source = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                             "workload, %s, kernel sources %s)" % (tr.get("tag", "?"), tr["kernel_source_hash"])
+        else:
+            traffic_source = "none for this kernel source (profiles/traffic_latest.json is from other kernel code)"
     except Exception:
-        traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(kernels[dom]["achieved_gbs"], 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kernels[dom]["achieved_gbs"] / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
+        traffic_source = "profiles/traffic_latest.json missing"
+    ach = kernels[dom]["achieved_gbs"]
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "peak_measured": round(peak_copy, 1), "frac_measured": round(ach / peak_copy, 4) if peak_copy else None,
+                "peak_measured_what": "copy kernel (read + write counted) over 1 GiB on this device, in this run; "
+                                      "read-only %.0f GB/s, write-only %.0f GB/s" % (peak_read, peak_write),
                 "avg_launch_ms": round(kernels[dom]["avg_ms"], 4),
                 "alg_bytes_per_launch": int(kernels[dom]["alg_bytes_per_launch"]),
-                "pipeline_achieved": round((recon_alg + post_alg) * args.steps / elapsed / 1e9, 1),
+                "pipeline_achieved": round((recon_alg + post_alg) * frames_per_step * args.steps / elapsed / 1e9, 1),
+                "pipeline_frac": round((recon_alg + post_alg) * frames_per_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
                 "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                                 "alg_bytes_per_launch": int(v["alg_bytes_per_launch"]),
-                                "achieved_gbs": round(v["achieved_gbs"], 1)} for k, v in kernels.items()}}
+                                "achieved_gbs": round(v["achieved_gbs"], 1)} for k, v in kernels.items()},
+                "k_recon_p_alg_bytes_per_launch": int(recon_alg_p)}
 
     extra = {}
     if rank == 0 and world == 1 and not args.no_extra:
         # BASELINE configs[1]: dense 1080p I pictures (every block Full): dequant + IDCT + YUV->RGBA, no deblock
         del wl
-        dense = Workload(n, 1, 0, local_rank, stream, i_kind=h263mi.SYNTH_I_DENSE, p_frames=False)
+        dense = Workload(h263mi, n, 1, 0, local_rank, stream, i_kind=h263mi.SYNTH_I_DENSE, p_frames=False)
         fr = dense.frames[0]
         for it in range(3):
             batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
             batch.render_rgba(0, d_rgba.ptr, None)
         batch.sync()
-        reps = 20
+        reps = 200
+        batch.timing_reserve(2 * reps)
         batch.timing_begin()
         t1 = time.perf_counter()
         for it in range(reps):
@@ -231,26 +393,33 @@ def main():
             "mp_per_s": round(n * reps * MP_PER_PICTURE / dt, 1),
             "k_recon_avg_ms": round(kd.recon_ms / max(kd.recon_launches, 1), 4),
             "k_post_avg_ms": round(kd.post_ms / max(kd.post_launches, 1), 4),
-            "alg_bytes_per_picture": int(alg / n), "pipeline_gbs": round(alg * reps / dt / 1e9, 1)}
+            "alg_bytes_per_picture": int(alg / n), "pipeline_gbs": round(alg * reps / dt / 1e9, 1),
+            "pipeline_frac": round(alg * reps / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
     out = {
         "metric": "decoded megapixels/sec (IDCT+MC+YUV->RGB)",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: batch of %d independent 1920x1080 streams per GPU; step = one "
-                               "frame index over the batch; GOP %d = 1 I (mixed block classes) + %d P (half-pel MVs "
-                               "in [-32,31], 25%% coded blocks, quant 10); dequant+IDCT+MC+add/clip, deblock "
-                               "strength %d, BT.601 RGBA; records pre-generated in HBM" % (n, args.gop, args.gop - 1, STRENGTH),
-                   "streams_per_gpu": n, "width": W, "height": H, "gop": args.gop,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8/i16/i32 integer + f32 (IDCT, un-fused)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: batch of %d independent 1920x1080 streams per GPU; step = one pass "
+                               "over the resident input = %d GOPs x %d frame indices = %d pictures per stream (%d per "
+                               "step and GPU); GOP = 1 I (mixed block classes) + %d P (half-pel MVs in [-32,31], 25%% "
+                               "coded blocks, quant 10); dequant+IDCT+MC+add/clip, deblock strength %d, BT.601 RGBA; "
+                               "records pre-generated in HBM" % (n, args.gops_per_step, args.gop, frames_per_step,
+                                                                 n * frames_per_step, args.gop - 1, STRENGTH),
+                   "streams_per_gpu": n, "width": W, "height": H, "gop": args.gop, "gops_per_step": args.gops_per_step,
+                   "pictures_per_step": n * frames_per_step * world,
                    "parallelism": "streams sharded per GPU, no data-path collective"},
+        "timed_region_s": round(elapsed, 4),
+        "ms_per_frame_index": round(elapsed / max(args.steps * frames_per_step, 1) * 1e3, 4),
         "realtime_1080p30_streams": round(value / (MP_PER_PICTURE * 30), 1),
+        "parity_gate": gate, "parity_gate_streams": gate_streams,
         "roofline": roofline,
     }
     if extra:
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(h263mi)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
@@ -258,7 +427,8 @@ def main():
     batch.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 1 if gate_bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -6,6 +6,7 @@
 
 #include <new>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -85,7 +86,14 @@ struct h263mi_batch {
     bool has_ref = false;                      // state.rs:29-31 reference_picture.is_some()
     uint32_t *d_status = nullptr;
     uint32_t *h_status = nullptr;              // pinned
-    uint64_t coeff_pool_blocks = 0;            // 0 = unchecked
+    uint64_t coeff_pool_blocks = 0;            // size of the pool the next submit reads ...
+    bool coeff_checked = false;                // ... when the caller told us (host entry points do; device pointers do not)
+    // what sync() falls back to when the device reports an error (state.rs:142, 464-487: an error leaves the state
+    // unchanged): the bookkeeping as of the last successful sync, valid as long as at most one picture was
+    // submitted since (the frame set it names is the one the ping-pong has not overwritten yet)
+    int good_cur = -1;
+    bool good_has_ref = false;
+    unsigned unsynced_submits = 0;
     // host-record staging for h263mi_batch_submit_host: two slots (pinned host + device) used alternately, so
     // that packing picture i+1 overlaps the copy and the kernel of picture i
     struct HostStaging {
@@ -116,9 +124,17 @@ struct h263mi_batch {
             HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t), hipHostMallocDefault));
         }
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
-        cur = -1;
-        has_ref = false;
+        cur = good_cur = -1;
+        has_ref = good_has_ref = false;
+        unsynced_submits = 0;
         return H263MI_OK;
+    }
+
+    void forget_pictures()
+    {
+        cur = good_cur = -1;
+        has_ref = good_has_ref = false;
+        unsynced_submits = 0;
     }
 
     void release_frames()
@@ -232,6 +248,7 @@ struct h263mi_batch {
         a.cur = frames[out];
         a.status = d_status;
         a.coeff_pool_blocks = coeff_pool_blocks;
+        a.coeff_checked = coeff_checked ? 1u : 0u;
         a.n_pictures = n;
         a.mbs_per_picture = L.mbw * L.mbh;
         a.has_ref = (has_ref && cur >= 0) ? 1u : 0u;
@@ -244,6 +261,7 @@ struct h263mi_batch {
         RC_TRY(time_end(0));
         if (overlap_post) HIP_TRY(hipEventRecord(ev_recon_done, stream));
         // reference bookkeeping, state.rs:464-483
+        unsynced_submits++;
         if (picture_type == H263MI_PICTURE_I) has_ref = false;
         cur = out;
         if (picture_type != H263MI_PICTURE_DISPOSABLE_P) has_ref = true;
@@ -279,10 +297,26 @@ struct h263mi_batch {
         HIP_TRY(hipStreamSynchronize(stream));
         uint32_t st = *h_status;
         if (st) {
+            // A picture the device rejected must not become the last / reference picture.  One picture since the
+            // last good sync: the previous frame set is intact, go back to it.  More than one: the set it lived in
+            // has been overwritten by the ping-pong, so no picture survives (like a reset).
+            if (unsynced_submits <= 1) {
+                cur = good_cur;
+                has_ref = good_has_ref;
+            } else {
+                cur = -1;
+                has_ref = false;
+            }
+            good_cur = cur;
+            good_has_ref = has_ref;
+            unsynced_submits = 0;
             HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
             if (st & STATUS_INTER_WITHOUT_REFERENCE) return H263MI_ERR_UNCODED_IFRAME_BLOCKS;
             return H263MI_ERR_INVALID_ARGUMENT;
         }
+        good_cur = cur;
+        good_has_ref = has_ref;
+        unsynced_submits = 0;
         return H263MI_OK;
     }
 
@@ -312,6 +346,7 @@ static int check_device(int device_id)
 static int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi_backend_cfg *cfg, h263mi_batch **out)
 {
     if (!out || !n_streams || !w || !h) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!layout_fits(w, h)) return H263MI_ERR_PICTURE_FORMAT_INVALID;        // before anything is allocated
     const int dev = cfg ? cfg->device_id : 0;
     RC_TRY(check_device(dev));
     DeviceGuard g(dev);
@@ -480,7 +515,22 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
 {
     if (!b || !d_mbs || picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
+    b->coeff_checked = false;                    // the size of a caller-owned device pool is not known here
+    b->coeff_pool_blocks = 0;
     return b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base);
+}
+
+int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs, const int16_t *d_coeffs,
+                        const uint64_t *d_coeff_base, uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba,
+                        uint8_t *d_deblocked)
+{
+    if (!b || !d_mbs || picture_type > H263MI_PICTURE_RESERVED || strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    b->coeff_checked = coeff_pool_blocks != 0;
+    b->coeff_pool_blocks = coeff_pool_blocks;
+    RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
+    if (!d_rgba && !d_deblocked) return H263MI_OK;
+    return b->render(strength, d_rgba, d_deblocked);
 }
 
 }  // extern "C"
@@ -528,11 +578,17 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         ev_base[i + 1] = ev_base[i] + (sparse ? n_events[i] : 0);
     }
     uint32_t *h_first = g2.h_events, *h_ev = sparse ? g2.h_events + blocks + 1 : nullptr;
-    bool offsets_ok = true;
+    std::atomic<bool> offsets_ok{true}, records_ok{true};
     // packing is a host memcpy of every record byte: a few threads, or one core caps the rate below the PCIe link
     auto pack = [&](uint32_t first, uint32_t last) {
         for (uint32_t i = first; i < last; i++) {
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
+            for (uint32_t k = 0; k < n_mbs[i]; k++) {                   // the same checks as h263mi_submit_picture
+                const MbRecord &m = mbs[i][k];
+                if (m.mb_type > H263MI_MB_INTER4V_Q || m.quant < 1 || m.quant > 31 || (m.cbp & 0xC0) || (m.kill & 0xC0) ||
+                    (uint64_t)m.coeff_index + (uint64_t)__builtin_popcount(m.cbp) > n_coeff_blocks[i])
+                    records_ok.store(false, std::memory_order_relaxed);
+            }
             if (n_mbs[i]) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
             for (size_t k = n_mbs[i]; k < per; k++) dst[k] = pad;
             if (!n_coeff_blocks[i]) continue;
@@ -541,7 +597,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             } else {
                 uint32_t *fo = h_first + g2.h_base[i];
                 for (uint32_t k = 0; k < n_coeff_blocks[i]; k++) {
-                    if (first_event[i][k] > first_event[i][k + 1]) offsets_ok = false;    // (benign race: only ever set to false)
+                    if (first_event[i][k] > first_event[i][k + 1]) offsets_ok.store(false, std::memory_order_relaxed);
                     fo[k] = first_event[i][k] + ev_base[i];
                 }
                 if (n_events[i]) memcpy(h_ev + ev_base[i], events[i], (size_t)n_events[i] * sizeof(uint32_t));
@@ -558,7 +614,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             pool.emplace_back(pack, (uint32_t)((uint64_t)b->n * t / n_thr), (uint32_t)((uint64_t)b->n * (t + 1) / n_thr));
         for (std::thread &t : pool) t.join();
     }
-    if (!offsets_ok) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
     HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, (size_t)b->n * per * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     if (sparse && blocks) {
@@ -574,6 +630,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
     }
     b->coeff_pool_blocks = blocks;
+    b->coeff_checked = true;
     RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base));
     HIP_TRY(hipEventRecord(g2.done, b->stream));
     b->host_slot++;
@@ -613,8 +670,7 @@ int h263mi_batch_sync(h263mi_batch *b)
 int h263mi_batch_reset(h263mi_batch *b)
 {
     if (!b) return H263MI_ERR_INVALID_ARGUMENT;
-    b->cur = -1;
-    b->has_ref = false;
+    b->forget_pictures();
     return H263MI_OK;
 }
 
@@ -631,6 +687,19 @@ int h263mi_batch_timing_begin(h263mi_batch *b)
     b->timing = true;
     b->ev_used = 0;
     b->ev_ranges.clear();
+    return H263MI_OK;
+}
+
+int h263mi_batch_timing_reserve(h263mi_batch *b, uint32_t n_launches)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    while (b->ev_pool.size() < 2 * (size_t)n_launches) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        b->ev_pool.push_back(e);
+    }
+    b->ev_ranges.reserve(n_launches);
     return H263MI_OK;
 }
 
@@ -671,6 +740,7 @@ int h263mi_state_new(uint32_t decoder_options, const h263mi_backend_cfg *cfg, h2
     s->options = decoder_options;
     if (cfg) s->cfg = *cfg;
     s->cfg.device_id = dev;
+    s->cfg.flags &= ~H263MI_CFG_OVERLAP_POST;    // batches only: h263mi_render_rgba copies back on the main stream
     *out = s;
     return H263MI_OK;
 }
@@ -684,10 +754,7 @@ int h263mi_state_reset(h263mi_state *s)
     if (!s) return H263MI_ERR_INVALID_ARGUMENT;
     s->has_last = false;
     s->parser_ctx = bits::ParserContext();
-    if (s->b) {
-        s->b->cur = -1;
-        s->b->has_ref = false;
-    }
+    if (s->b) s->b->forget_pictures();
     return H263MI_OK;
 }
 
@@ -713,7 +780,7 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
         for (size_t i = 0; i < n_coeff_blocks; i++)
             if (first_event[i] > first_event[i + 1]) return H263MI_ERR_INVALID_ARGUMENT;
     }
-    if (!desc->width || !desc->height) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+    if (!desc->width || !desc->height || !layout_fits(desc->width, desc->height)) return H263MI_ERR_PICTURE_FORMAT_INVALID;
     if (desc->picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;
     const FrameLayout L = make_layout(desc->width, desc->height);
     const size_t total = (size_t)L.mbw * L.mbh;
@@ -775,6 +842,7 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
     }
 
     b->coeff_pool_blocks = n_coeff_blocks;
+    b->coeff_checked = true;
     RC_TRY(b->submit(desc->picture_type, g2.d_mbs, g2.d_coeffs, nullptr));
     HIP_TRY(hipEventRecord(g2.done, b->stream));
     s->next_slot++;
@@ -913,6 +981,7 @@ int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t streng
     if (!data || !out || !width || len % width != 0 || strength < 1 || strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
     const size_t height = len / width;
     if (!height || width > 65535 || height > 65535) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!layout_fits(width, height)) return H263MI_ERR_OUT_OF_MEMORY;          // frame offsets are 32-bit on the device
     RC_TRY(check_device(0));
     DeviceGuard g(0);
     const FrameLayout L = make_layout((uint32_t)width, (uint32_t)height);
@@ -944,6 +1013,7 @@ int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len, const uint8_t *c
     if (!y || !chroma_b || !chroma_r || !rgba_out || !y_width || y_len % y_width != 0) return H263MI_ERR_INVALID_ARGUMENT;
     const size_t h = y_len / y_width, cw = (y_width + 1) / 2, ch = (h + 1) / 2;   // bt601.rs:115-126
     if (c_len != cw * ch || y_width > 65535 || h > 65535) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!layout_fits(y_width, h)) return H263MI_ERR_OUT_OF_MEMORY;
     RC_TRY(check_device(0));
     DeviceGuard g(0);
     const FrameLayout L = make_layout((uint32_t)y_width, (uint32_t)h);
@@ -1023,6 +1093,42 @@ int h263mi_device_synchronize(int device_id)
     RC_TRY(check_device(device_id));
     DeviceGuard g(device_id);
     HIP_TRY(hipDeviceSynchronize());
+    return H263MI_OK;
+}
+
+int h263mi_probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s)
+{
+    if (!gb_per_s || mode < 0 || mode > 2 || bytes < (1u << 20) || reps < 1) return H263MI_ERR_INVALID_ARGUMENT;
+    const int dev = cfg ? cfg->device_id : 0;
+    RC_TRY(check_device(dev));
+    DeviceGuard g(dev);
+    hipStream_t stream = cfg ? (hipStream_t)cfg->stream : nullptr;
+    bytes &= ~(size_t)15;
+    TempBuf in, out;
+    if (mode != 2) {
+        HIP_TRY(hipMalloc(&in.p, bytes));
+        HIP_TRY(hipMemsetAsync(in.p, 1, bytes, stream));
+    }
+    HIP_TRY(hipMalloc(&out.p, mode == 1 ? 16 : bytes));
+    HIP_TRY(hipMemsetAsync(out.p, 0, mode == 1 ? 16 : bytes, stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return H263MI_ERR_HIP;
+    }
+    hipError_t e = launch_probe(mode, in.p, out.p, bytes, stream);            // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, stream);
+    for (int i = 0; i < reps && e == hipSuccess; i++) e = launch_probe(mode, in.p, out.p, bytes, stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(e);
+    const double moved = (mode == 0 ? 2.0 : 1.0) * (double)bytes * reps;
+    *gb_per_s = ms > 0.f ? moved / (ms * 1e-3) / 1e9 : 0.0;
     return H263MI_OK;
 }
 

@@ -64,6 +64,19 @@ H263_HD FrameLayout make_layout(uint32_t w, uint32_t h)
     return L;
 }
 
+// Every offset inside a frame is a 32-bit quantity on the device.  Pictures whose frame store would not fit
+// kMaxFrameBytes (1 GiB: e.g. 26 000 x 26 000) are rejected by the host entry points BEFORE anything is allocated
+// or launched: the 16-bit width / height of a Sorenson custom format come straight from an untrusted bitstream.
+constexpr uint64_t kMaxFrameBytes = 1ull << 30;
+inline bool layout_fits(uint64_t w, uint64_t h)
+{
+    if (!w || !h || w > 65535 || h > 65535) return false;
+    const uint64_t mbw = (w + 15) / 16, mbh = (h + 15) / 16;
+    const uint64_t pitch_c = ((mbw * 8 + 63) / 64) * 64;
+    const uint64_t bytes = 2 * pitch_c * mbh * 16 + 2 * pitch_c * mbh * 8 + 512;
+    return bytes <= kMaxFrameBytes;
+}
+
 typedef h263mi_mb_record MbRecord;
 static_assert(sizeof(MbRecord) == 32, "record layout is part of the ABI");
 
@@ -84,7 +97,8 @@ struct ReconArgs {
     const uint8_t *ref;          // reference frames (picture p at + p*frame_bytes); never null
     uint8_t *cur;                // output frames
     uint32_t *status;            // device status word
-    uint64_t coeff_pool_blocks;  // size of the pool, for the bounds check (0 = unchecked)
+    uint64_t coeff_pool_blocks;  // size of the pool (blocks), used when coeff_checked is set
+    uint32_t coeff_checked;      // 1: a coded block whose index is >= coeff_pool_blocks is an error (and is not read)
     uint32_t n_pictures;
     uint32_t mbs_per_picture;
     uint32_t has_ref;            // 0: inter macroblocks are an error

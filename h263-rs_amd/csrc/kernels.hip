@@ -33,6 +33,13 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 #else
 #define PHASE_MARK(i) do { } while (0)
 #endif
+// H263MI_ISA_MARKERS: comments in the generated assembly at the phase boundaries, for tools/isa_mix.py (a static
+// per-phase instruction-mix table of the disassembly); emits no instruction
+#if defined(H263MI_ISA_MARKERS)
+#define ISA_MARK(name) asm volatile("; ISA_MARK " name)
+#else
+#define ISA_MARK(name) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
@@ -66,7 +73,9 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 #if defined(H263MI_PROFILE_PHASES)
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
+    ISA_MARK("prologue_end");
     recon_phase_load(a, s, lane, p);
+    ISA_MARK("load_end");
     PHASE_MARK(0);                                  // records requested and in LDS
     // `ln`: the lane index behind an opaque asm, re-derived per phase so that lane-only expressions are
     // recomputed where they are used instead of being kept in registers across the whole kernel
@@ -79,16 +88,20 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
         km.act = km.inter = 0;
         recon_phase_mark(a, s, ln, p, km);
         recon_phase_compact(a, s, ln, km);
+        ISA_MARK("mark_end");
         PHASE_MARK(1);
         WaveFetch f;
         recon_phase_fetch(a, s, f, ln, p, km);      // every global load of this half is in flight from here
         const int n_active = recon_n_active(km);
+        ISA_MARK("fetch_end");
         PHASE_MARK(2);
 #pragma unroll 1
         for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
             asm volatile("" : "+v"(ln));
             RowIn ri;
+            ISA_MARK("round_begin");
             recon_phase_idct_load(a, s, f, ln, p, round, ri, km);
+            ISA_MARK("idct_load_end");
             // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
             const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
                                 (__ballot(ri.w[3] != 0) ? 8u : 0u);
@@ -97,7 +110,9 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
             rows_mask |= rows_mask >> 16;
             rows_mask |= rows_mask >> 8;
             asm volatile("" : "+v"(ln));
+            ISA_MARK("idct_rows_end");
             recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu), km);
+            ISA_MARK("idct_cols_end");
         }
         PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
 #if defined(H263MI_PROFILE_PHASES)
@@ -105,7 +120,9 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
         PHASE_MARK(4);                              // reference rows have arrived
 #endif
         asm volatile("" : "+v"(ln));
+        ISA_MARK("output_begin");
         recon_phase_output(a, s, f, ln, p, km);
+        ISA_MARK("output_end");
         PHASE_MARK(5);
     }
 }
@@ -300,6 +317,39 @@ hipError_t launch_synth_coeffs(const SynthArgs &a, hipStream_t stream)
 {
     const uint32_t n = a.n_streams * a.mbs_per_picture * 6;
     hipLaunchKernelGGL(k_synth_coeffs, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// on-box memory ceilings (bench support: roofline.peak_measured).  Plain grid-stride streaming kernels with
+// 16-byte accesses: the rate the HBM system of THIS box sustains for a copy, a pure read and a pure write.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_probe_read(const uint4 *__restrict__ in, uint4 *__restrict__ sink, size_t n)
+{
+    uint32_t acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = make_uint4(acc, 0, 0, 0);      // never true for the probe's fill pattern
+}
+__global__ __launch_bounds__(256) void k_probe_write(uint4 *__restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = make_uint4((uint32_t)i, 1, 2, 3);
+}
+
+hipError_t launch_probe(int mode, const void *in, void *out, size_t bytes, hipStream_t stream)
+{
+    const size_t n = bytes / 16;
+    const dim3 grid(256 * 8), block(256);
+    if (mode == 0) hipLaunchKernelGGL(k_probe_copy, grid, block, 0, stream, (const uint4 *)in, (uint4 *)out, n);
+    else if (mode == 1) hipLaunchKernelGGL(k_probe_read, grid, block, 0, stream, (const uint4 *)in, (uint4 *)out, n);
+    else hipLaunchKernelGGL(k_probe_write, grid, block, 0, stream, (uint4 *)out, n);
     return hipGetLastError();
 }
 

@@ -496,7 +496,7 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
             if ((rec.cbp >> blk) & 1) {
                 const uint64_t cidx = p.cbase + rec.coeff_index +
                                       (uint64_t)popc32(rec.cbp & ((1u << blk) - 1u));
-                if (!(a.coeff_pool_blocks && cidx >= a.coeff_pool_blocks))
+                if (!(a.coeff_checked && cidx >= a.coeff_pool_blocks))
                     src = reinterpret_cast<const uint8_t *>(a.coeffs + cidx * 64 + (size_t)r * 8);
             }
         }
@@ -569,7 +569,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     if ((rec.cbp >> blk) & 1) {
         const uint64_t cidx = p.cbase + rec.coeff_index +
                               (uint64_t)popc32(rec.cbp & ((1u << blk) - 1u));
-        if (a.coeff_pool_blocks && cidx >= a.coeff_pool_blocks) {
+        if (a.coeff_checked && cidx >= a.coeff_pool_blocks) {
             if (r == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 atomicOr(a.status, STATUS_COEFF_INDEX_OUT_OF_RANGE);

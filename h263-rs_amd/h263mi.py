@@ -63,8 +63,10 @@ EXPORTS = [
     "h263mi_get_last_picture", "h263mi_get_reference_picture", "h263mi_copy_yuv", "h263mi_render_rgba",
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
+    "h263mi_batch_decode",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
-    "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_submit_host", "h263mi_submit_picture_events", "h263mi_batch_submit_host_events",
+    "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_timing_reserve", "h263mi_probe_bandwidth",
+    "h263mi_batch_submit_host", "h263mi_submit_picture_events", "h263mi_batch_submit_host_events",
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
     "h263mi_synth_picture_host", "h263mi_synth_batch_device",
@@ -145,6 +147,7 @@ def lib():
         L.h263mi_batch_mbs_per_picture.argtypes = [vp]
         L.h263mi_batch_mbs_per_picture.restype = u32
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
+        L.h263mi_batch_decode.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp]
         L.h263mi_batch_submit_host.argtypes = [vp, u8, vp, vp, vp, vp]
         L.h263mi_batch_submit_host_events.argtypes = [vp, u8, vp, vp, vp, vp, vp, vp]
         L.h263mi_batch_render_rgba.argtypes = [vp, u8, vp, vp]
@@ -153,6 +156,8 @@ def lib():
         L.h263mi_batch_copy_yuv.argtypes = [vp, u32, vp, vp, vp]
         L.h263mi_batch_timing_begin.argtypes = [vp]
         L.h263mi_batch_timing_end.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.h263mi_batch_timing_reserve.argtypes = [vp, u32]
+        L.h263mi_probe_bandwidth.argtypes = [C.POINTER(BackendCfg), i32, sz, i32, C.POINTER(C.c_double)]
         L.h263mi_device_count.argtypes = [C.POINTER(i32)]
         L.h263mi_device_malloc.argtypes = [i32, sz, C.POINTER(vp)]
         L.h263mi_device_free.argtypes = [i32, vp]
@@ -244,9 +249,9 @@ class DecodedPicture:
 class H263State:
     """H263State (h263/src/decoder/state.rs:16-490) over the C ABI."""
 
-    def __init__(self, decoder_options=SORENSON_SPARK_BITSTREAM, device_id=0, stream=None):
+    def __init__(self, decoder_options=SORENSON_SPARK_BITSTREAM, device_id=0, stream=None, cfg_flags=0):
         self._h = C.c_void_p()
-        self._cfg = BackendCfg(device_id, 0, stream)
+        self._cfg = BackendCfg(device_id, cfg_flags, stream)
         _check(lib().h263mi_state_new(decoder_options, C.byref(self._cfg), C.byref(self._h)), "H263State::new")
 
     def close(self):
@@ -392,6 +397,12 @@ class Batch:
     def submit(self, picture_type, d_mbs, d_coeffs, d_coeff_base=None):
         _check(lib().h263mi_batch_submit(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base), "batch_submit")
 
+    def decode(self, picture_type, d_mbs, d_coeffs, d_coeff_base=None, coeff_pool_blocks=0, strength=0, d_rgba=None,
+               d_deblocked=None):
+        """submit + render_rgba in one call (h263mi_batch_decode)"""
+        _check(lib().h263mi_batch_decode(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength,
+                                         d_rgba, d_deblocked), "batch_decode")
+
     def submit_host(self, picture_type, mbs_list, coeffs_list):
         """one picture per stream from host records: lists of MB_RECORD_DTYPE arrays and (n, 64) int16 arrays"""
         n = len(mbs_list)
@@ -436,10 +447,24 @@ class Batch:
     def timing_begin(self):
         _check(lib().h263mi_batch_timing_begin(self._h), "timing_begin")
 
+    def timing_reserve(self, n_launches):
+        _check(lib().h263mi_batch_timing_reserve(self._h, n_launches), "timing_reserve")
+
     def timing_end(self):
         t = KernelTimes()
         _check(lib().h263mi_batch_timing_end(self._h, C.byref(t)), "timing_end")
         return t
+
+
+PROBE_COPY, PROBE_READ, PROBE_WRITE = 0, 1, 2
+
+
+def probe_bandwidth(mode, nbytes=1 << 30, reps=10, device_id=0, stream=None):
+    """GB/s the device sustains for a plain streaming copy / read / write kernel (h263mi_probe_bandwidth)."""
+    cfg = BackendCfg(device_id, 0, stream)
+    out = C.c_double(0.0)
+    _check(lib().h263mi_probe_bandwidth(C.byref(cfg), mode, nbytes, reps, C.byref(out)), "probe_bandwidth")
+    return out.value
 
 
 def synth_picture_host(kind, width, height, stream_id, frame_idx):

@@ -120,8 +120,7 @@ VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0)
         if (l > max_len_) max_len_ = l;
     }
     lut_.assign((size_t)1 << max_len_, Slot{0, 0, 0, 0, 0});
-    for (size_t i = 0; i < n; i++)          // payloads are small by construction (types, runs <= 40, levels <= 12, vectors +-32)
-        if (codes[i].v0 < -128 || codes[i].v0 > 127 || codes[i].v1 < -128 || codes[i].v1 > 127 || codes[i].v2 < -128 || codes[i].v2 > 127) abort();
+    // (payloads fit the 8-bit slot fields: checked at compile time, see H263MI_TABLE)
     // For every max_len_-bit pattern: the length at which a bit-by-bit walk of the code tree stops --
     // either on a code word, or on the shortest prefix that no code word starts with (the tree's
     // "invalid" leaves).
@@ -168,7 +167,19 @@ int VlcTable::decode(BitReader &r, VlcHit &hit) const
 
 #include "vlc_tables.inc"
 
+// the LUT slots keep the payloads in 8 bits: types, runs <= 40, levels <= 12, vectors +-32 all fit (checked here,
+// at compile time, for every generated table)
+template <size_t N> static constexpr bool payloads_fit_i8(const VlcCode (&codes)[N])
+{
+    for (size_t i = 0; i < N; i++)
+        if (codes[i].v0 < -128 || codes[i].v0 > 127 || codes[i].v1 < -128 || codes[i].v1 > 127 || codes[i].v2 < -128 ||
+            codes[i].v2 > 127)
+            return false;
+    return true;
+}
+
 #define H263MI_TABLE(fn, arr)                                                   \
+    static_assert(payloads_fit_i8(arr), "VLC payload does not fit a LUT slot"); \
     const VlcTable &fn()                                                        \
     {                                                                           \
         static const VlcTable t(arr, sizeof(arr) / sizeof(arr[0]));             \

@@ -268,6 +268,22 @@ uint32_t h263mi_batch_mbs_per_picture(const h263mi_batch *b);
 int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
                         const h263mi_mb_record *d_mbs, const int16_t *d_coeffs,
                         const uint64_t *d_coeff_base);
+/*
+ * Decode + post-process in ONE call: h263mi_batch_submit followed by h263mi_batch_render_rgba (d_rgba / d_deblocked as
+ * there; both NULL = reconstruction only).  Knowing both halves up front lets the library order the work so that
+ * the reconstructed planes are still on chip when they are filtered and converted.  coeff_pool_blocks is the size of
+ * d_coeffs in 64-coefficient blocks: a coded block that would lie outside is not read and makes the next
+ * h263mi_batch_sync fail with H263MI_ERR_INVALID_ARGUMENT (0 = size unknown, nothing is checked).
+ *
+ * Errors the device detects (this one; an inter macroblock without a reference picture) surface at the next
+ * h263mi_batch_sync.  The batch then forgets the rejected picture, as the reference leaves its state unchanged on any
+ * error (state.rs:142, 464-487): if one picture was submitted since the last successful sync, the picture before
+ * it is the last picture again; if several were, none survives (their frame sets have been reused) and the batch
+ * is as after h263mi_batch_reset.
+ */
+int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
+                        const h263mi_mb_record *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
+                        uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 /* deblock (strength 0 = off) + BT.601 of every stream's last picture into d_rgba
  * (DEVICE, n_streams * w*h*4 bytes, stream-major); d_deblocked (DEVICE, may be NULL)
  * additionally receives the filtered planes, n_streams * (w*h + 2*cw*ch) bytes as
@@ -279,7 +295,9 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
  * (coeff_index counts from the stream's own first block).  The arrays are packed into pinned staging -- two slots,
  * used alternately, so packing picture i+1 overlaps the copy and the kernel of picture i -- copied with one
  * asynchronous H2D per array and decoded by one k_recon launch.  The host arrays may be reused on return.
- * Records are not validated here beyond the counts; errors surface at h263mi_batch_sync like for h263mi_batch_submit.
+ * Records are validated like h263mi_submit_picture validates them (types, quantiser, coded block indices against
+ * n_coeff_blocks[s]; H263MI_ERR_INVALID_ARGUMENT before anything is queued); an inter macroblock without a
+ * reference picture surfaces at h263mi_batch_sync like for h263mi_batch_submit.
  */
 int h263mi_batch_submit_host(h263mi_batch *b, uint8_t picture_type,
                              const h263mi_mb_record *const *mbs, const uint32_t *n_mbs,
@@ -303,6 +321,9 @@ typedef struct h263mi_kernel_times {
 } h263mi_kernel_times;
 int h263mi_batch_timing_begin(h263mi_batch *b);
 int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out);
+/* Create the events for `n_launches` timed kernel launches ahead of time, so that none is created inside a
+ * timed region. */
+int h263mi_batch_timing_reserve(h263mi_batch *b, uint32_t n_launches);
 
 /* ======================================================================= */
 /* Device memory + synthetic macroblock records (bench / test support)      */
@@ -313,6 +334,14 @@ int h263mi_device_free(int device_id, void *p);
 int h263mi_device_memcpy_h2d(int device_id, void *dst, const void *src, size_t bytes);
 int h263mi_device_memcpy_d2h(int device_id, void *dst, const void *src, size_t bytes);
 int h263mi_device_synchronize(int device_id);
+
+/* On-box memory ceiling of the device (bench support, BASELINE.md section 4 "measure an on-box copy-kernel
+ * ceiling"): streams `bytes` through a plain grid-stride kernel `reps` times on cfg's stream and reports the rate.
+ * mode 0: copy (bytes read + bytes written are both counted), 1: read only, 2: write only. */
+#define H263MI_PROBE_COPY  0
+#define H263MI_PROBE_READ  1
+#define H263MI_PROBE_WRITE 2
+int h263mi_probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s);
 
 #define H263MI_SYNTH_I_DENSE 0  /* BASELINE config 2 "dense": every block Full */
 #define H263MI_SYNTH_I_MIXED 1  /* config 2 "mixed": Dc / Horiz / Vert / Full-dense / Full-sparse */

@@ -44,43 +44,48 @@ def build(force=False):
 _lib = None
 
 
+def bind(L):
+    """declare the orc_* signatures on a loaded library handle (the portable build below, or the native one of
+    oracle/native_bench.py)"""
+    u8p = C.POINTER(C.c_uint8)
+    L.orc_intradc_into_level.restype = C.c_int16
+    L.orc_intradc_into_level.argtypes = [C.c_uint8]
+    L.orc_average_sum_of_mvs.restype = C.c_int16
+    L.orc_average_sum_of_mvs.argtypes = [C.c_int16]
+    L.orc_lerp_parameters.restype = None
+    L.orc_lerp_parameters.argtypes = [C.c_int16, C.POINTER(C.c_int16), C.POINTER(C.c_int)]
+    L.orc_inverse_rle.restype = None
+    L.orc_inverse_rle.argtypes = [C.POINTER(Block), C.POINTER(DctBlock), C.c_size_t, C.c_size_t,
+                                  C.c_size_t, C.c_uint8]
+    L.orc_idct_channel.restype = None
+    L.orc_idct_channel.argtypes = [C.POINTER(DctBlock), C.c_size_t, C.c_void_p, C.c_size_t,
+                                   C.c_size_t, C.c_size_t]
+    L.orc_gather.restype = C.c_int
+    L.orc_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_decode_picture.restype = C.c_int
+    L.orc_decode_picture.argtypes = [C.c_uint16, C.c_uint16, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_deblock.restype = C.c_int
+    L.orc_deblock.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint8, C.c_void_p]
+    for name in ("orc_deblock_process_scalar", "orc_deblock_process_simd_lane"):
+        f = getattr(L, name)
+        f.restype = None
+        f.argtypes = [u8p, u8p, u8p, u8p, C.c_uint8]
+    L.orc_yuv420_to_rgba.restype = C.c_int
+    L.orc_yuv420_to_rgba.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_size_t, C.c_void_p]
+    L.orc_basis_table.restype = C.POINTER(C.c_float)
+    L.orc_basis_table.argtypes = []
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
-        u8p = C.POINTER(C.c_uint8)
-        L.orc_intradc_into_level.restype = C.c_int16
-        L.orc_intradc_into_level.argtypes = [C.c_uint8]
-        L.orc_average_sum_of_mvs.restype = C.c_int16
-        L.orc_average_sum_of_mvs.argtypes = [C.c_int16]
-        L.orc_lerp_parameters.restype = None
-        L.orc_lerp_parameters.argtypes = [C.c_int16, C.POINTER(C.c_int16), C.POINTER(C.c_int)]
-        L.orc_inverse_rle.restype = None
-        L.orc_inverse_rle.argtypes = [C.POINTER(Block), C.POINTER(DctBlock), C.c_size_t, C.c_size_t,
-                                      C.c_size_t, C.c_uint8]
-        L.orc_idct_channel.restype = None
-        L.orc_idct_channel.argtypes = [C.POINTER(DctBlock), C.c_size_t, C.c_void_p, C.c_size_t,
-                                       C.c_size_t, C.c_size_t]
-        L.orc_gather.restype = C.c_int
-        L.orc_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_decode_picture.restype = C.c_int
-        L.orc_decode_picture.argtypes = [C.c_uint16, C.c_uint16, C.c_void_p, C.c_size_t, C.c_void_p,
-                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_deblock.restype = C.c_int
-        L.orc_deblock.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint8, C.c_void_p]
-        for name in ("orc_deblock_process_scalar", "orc_deblock_process_simd_lane"):
-            f = getattr(L, name)
-            f.restype = None
-            f.argtypes = [u8p, u8p, u8p, u8p, C.c_uint8]
-        L.orc_yuv420_to_rgba.restype = C.c_int
-        L.orc_yuv420_to_rgba.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
-                                         C.c_size_t, C.c_void_p]
-        L.orc_basis_table.restype = C.POINTER(C.c_float)
-        L.orc_basis_table.argtypes = []
-        _lib = L
+        _lib = bind(C.CDLL(_LIB_PATH))
     return _lib
 
 
@@ -117,17 +122,17 @@ def process_simd_lane(a, b, c, d, strength):
     return tuple(x.value for x in v)
 
 
-def deblock(data, width, strength):
+def deblock(data, width, strength, L=None):
     """deblock::deblock(data, width, strength) -> new buffer (deblock.rs:305)."""
     data = np.ascontiguousarray(data, dtype=np.uint8).ravel()
     out = np.empty_like(data)
-    rc = lib().orc_deblock(_ptr(data), data.size, width, strength, _ptr(out))
+    rc = (L or lib()).orc_deblock(_ptr(data), data.size, width, strength, _ptr(out))
     if rc != 0:
         raise ValueError("orc_deblock rc=%d" % rc)
     return out
 
 
-def yuv420_to_rgba(y, cb, cr, y_width):
+def yuv420_to_rgba(y, cb, cr, y_width, L=None):
     """yuv::bt601::yuv420_to_rgba(y, chroma_b, chroma_r, y_width) (bt601.rs:105)."""
     y = np.ascontiguousarray(y, dtype=np.uint8).ravel()
     cb = np.ascontiguousarray(cb, dtype=np.uint8).ravel()
@@ -135,7 +140,7 @@ def yuv420_to_rgba(y, cb, cr, y_width):
     out = np.empty(y.size * 4, dtype=np.uint8)
     if cb.size != cr.size:
         raise ValueError("chroma size mismatch")
-    rc = lib().orc_yuv420_to_rgba(_ptr(y), y.size, _ptr(cb), _ptr(cr), cb.size, y_width, _ptr(out))
+    rc = (L or lib()).orc_yuv420_to_rgba(_ptr(y), y.size, _ptr(cb), _ptr(cr), cb.size, y_width, _ptr(out))
     if rc != 0:
         raise ValueError("orc_yuv420_to_rgba rc=%d" % rc)
     return out
@@ -184,7 +189,7 @@ def gather(mb_types, mvs, ref, width, height):
     return rc, (ny, ncb, ncr)
 
 
-def decode_picture(width, height, mbs, coeffs, ref=None):
+def decode_picture(width, height, mbs, coeffs, ref=None, L=None):
     """Record-level reconstruction (tail of decode_next_picture, state.rs:421-458).
 
     mbs: structured array MB_RECORD_DTYPE (len <= mbw*mbh); coeffs: int16[n_blocks, 64];
@@ -196,6 +201,6 @@ def decode_picture(width, height, mbs, coeffs, ref=None):
     ocb = np.empty(cw * ch, np.uint8)
     ocr = np.empty(cw * ch, np.uint8)
     r = [None, None, None] if ref is None else [np.ascontiguousarray(p, dtype=np.uint8).ravel() for p in ref]
-    rc = lib().orc_decode_picture(width, height, _ptr(mbs), mbs.size, _ptr(coeffs), coeffs.shape[0],
+    rc = (L or lib()).orc_decode_picture(width, height, _ptr(mbs), mbs.size, _ptr(coeffs), coeffs.shape[0],
                                   _ptr(r[0]), _ptr(r[1]), _ptr(r[2]), _ptr(oy), _ptr(ocb), _ptr(ocr))
     return rc, (oy, ocb, ocr)

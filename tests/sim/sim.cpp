@@ -31,6 +31,7 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
     a.cur = cur;
     a.status = status;
     a.coeff_pool_blocks = n_blocks;
+    a.coeff_checked = 1;
     a.n_pictures = n_pictures;
     a.mbs_per_picture = a.L.mbw * a.L.mbh;
     a.has_ref = has_ref;

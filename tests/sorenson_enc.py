@@ -20,7 +20,7 @@ _INC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "h263-rs_a
 def _load_tables():
     tables, cur = {}, None
     for line in open(_INC):
-        m = re.match(r"static const VlcCode (\w+)\[\]", line)
+        m = re.match(r"static constexpr VlcCode (\w+)\[\]", line)
         if m:
             cur = tables.setdefault(m.group(1), [])
             continue

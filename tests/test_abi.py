@@ -118,3 +118,22 @@ def test_kernel_isa_has_no_fused_multiply_add_and_no_compiler_selected_ashr_pk()
         elif "v_ashr_pk_" in line:
             assert in_asm, "compiler-selected v_ashr_pk: " + line
     assert "v_pk_mul_f32" in body or "v_mul_f32" in body
+
+
+def test_oversized_pictures_are_rejected_before_any_allocation():
+    """frame offsets are 32-bit on the device; a Sorenson custom format carries 16-bit width / height from
+    an untrusted bitstream.  53600 x 53600 would wrap frame_bytes to 17 MB: every entry point refuses such a size up
+    front (the check precedes the device check, so it is testable without a GPU)."""
+    import ctypes as C
+    L = h263mi.lib()
+    out = C.c_void_p()
+    cfg = h263mi.BackendCfg(0, 0, None)
+    assert L.h263mi_batch_create(1, 53600, 53600, C.byref(cfg), C.byref(out)) == h263mi.ERR_PICTURE_FORMAT_INVALID
+    assert L.h263mi_batch_create(1, 65535, 65535, C.byref(cfg), C.byref(out)) == h263mi.ERR_PICTURE_FORMAT_INVALID
+    dummy = (C.c_uint8 * 16)()
+    assert L.h263mi_deblock(dummy, 53600 * 53600, 53600, 5, dummy) == -103          # H263MI_ERR_OUT_OF_MEMORY
+    assert L.h263mi_bt601_yuv420_to_rgba(dummy, 53600 * 53600, dummy, dummy, 26800 * 26800, 53600, dummy) == -103
+    # a size that fits is not refused by the size check (it gets as far as the device check)
+    assert L.h263mi_batch_create(1, 1920, 1080, C.byref(cfg), C.byref(out)) in (h263mi.OK, h263mi.ERR_NO_DEVICE)
+    if out:
+        L.h263mi_batch_destroy(out)

@@ -1,0 +1,227 @@
+"""GPU tests added in round 2: BASELINE configs[3] at its stated size (64 streams), a bounded slice of the
+randomised differential run, the reference-store cases the record-level API had no GPU test for, and the error
+semantics of the batch API.  Everything goes through the C ABI and is compared with the oracle bit for bit."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import h263mi
+import recgen
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 1920, 1080
+MBS_PP = 120 * 68
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if h263mi.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests must run on the MI355X box")
+
+
+def assert_planes_equal(got, want, what=""):
+    for g, e, name in zip(got, want, ("Y", "Cb", "Cr")):
+        bad = np.flatnonzero(np.asarray(g) != np.asarray(e))
+        assert bad.size == 0, "%s %s: %d bytes differ, first at %s" % (what, name, bad.size, bad[:8])
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[3]: 64 independent 1080p streams in one batch, 1 I + 2 P, three streams against the oracle
+# ---------------------------------------------------------------------------------------------
+def test_64_stream_1080p_batch_matches_the_oracle_on_streams_0_31_63():
+    n, first_stream = 64, 7
+    b = h263mi.Batch(n, W, H)
+    d_rgba = h263mi.DeviceBuffer(n * W * H * 4)
+    refs = {0: None, 31: None, 63: None}
+    for f in range(3):
+        kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
+        cap = n * MBS_PP * (6 if f == 0 else 2)
+        d_mbs, d_co, d_base = h263mi.DeviceBuffer(n * MBS_PP * 32), h263mi.DeviceBuffer(cap * 128), h263mi.DeviceBuffer(n * 8)
+        total = h263mi.synth_batch_device(kind, W, H, n, first_stream, f, d_mbs.ptr, d_co.ptr, cap, d_base.ptr)
+        # the one-call form, with the pool bound in force
+        b.decode(h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, d_mbs.ptr, d_co.ptr, d_base.ptr, total, 5, d_rgba.ptr)
+        b.sync()
+        for s in refs:
+            mbs, co = h263mi.synth_picture_host(kind, W, H, first_stream + s, f)
+            rc, refs[s] = orc.decode_picture(W, H, mbs, co, refs[s])
+            assert rc == 0
+            assert_planes_equal(b.copy_yuv(s), refs[s], "stream %d frame %d" % (s, f))
+            filt = tuple(orc.deblock(p, pw, 5) for p, pw in zip(refs[s], (W, 960, 960)))
+            got = d_rgba.download(W * H * 4, s * W * H * 4)
+            assert (got == orc.yuv420_to_rgba(*filt, W)).all(), "RGBA stream %d frame %d" % (s, f)
+        for d in (d_mbs, d_co, d_base):
+            d.free()
+    b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# bounded slice of tools/fuzz_gpu.py (fixed seed)
+# ---------------------------------------------------------------------------------------------
+def test_fuzz_slice_fixed_seed():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+    n_pic, n_px = fuzz_gpu.run(budget=20.0, seed=20261003, verbose=False)
+    assert n_pic > 50
+
+
+# ---------------------------------------------------------------------------------------------
+# reference store: disposable P pictures and equal temporal references (state.rs:464-483, 72-78)
+# ---------------------------------------------------------------------------------------------
+def test_disposable_p_picture_at_record_level():
+    """A disposable P picture becomes the LAST picture but not the reference (state.rs:474-480); since
+    get_reference_picture hands out the last picture whenever a reference exists (state.rs:72-78, mirrored on
+    purpose), the next P picture predicts from the disposable one."""
+    w, h = 176, 144
+    st = h263mi.H263State()
+    mbs, co = recgen.inter_picture(w, h, seed=3)
+    with pytest.raises(h263mi.H263Error) as e:                   # nothing to predict from yet
+        st.submit_picture(w, h, mbs, co, h263mi.PICTURE_DISPOSABLE_P)
+    assert e.value.code == h263mi.ERR_UNCODED_IFRAME_BLOCKS and st.get_last_picture() is None
+    imbs, ico = recgen.intra_picture(w, h, seed=1)
+    st.submit_picture(w, h, imbs, ico, h263mi.PICTURE_I, temporal_reference=0)
+    rc, ref = orc.decode_picture(w, h, imbs, ico, None)
+    assert st.has_reference_picture()
+    for f, pt in enumerate((h263mi.PICTURE_DISPOSABLE_P, h263mi.PICTURE_DISPOSABLE_P, h263mi.PICTURE_P,
+                            h263mi.PICTURE_DISPOSABLE_P, h263mi.PICTURE_P), start=1):
+        mbs, co = recgen.inter_picture(w, h, seed=10 + f, mv_range=40, p_4v=0.3, p_intra=0.1, p_coded=0.4, quant=6)
+        st.submit_picture(w, h, mbs, co, pt, temporal_reference=f)
+        rc, ref = orc.decode_picture(w, h, mbs, co, ref)
+        assert rc == 0
+        pic = st.get_last_picture()
+        assert pic.picture_type == pt and pic.temporal_reference == f
+        assert_planes_equal(pic.as_yuv(), ref, "picture %d (type %d)" % (f, pt))
+        assert st.has_reference_picture()
+    st.close()
+
+
+def test_equal_consecutive_temporal_references():
+    """the reference store is keyed by temporal_reference (state.rs:29-38): a picture that re-uses the key of the
+    picture it predicts from must still read the OLD picture and then replace it"""
+    w, h = 100, 60
+    st = h263mi.H263State()
+    imbs, ico = recgen.intra_picture(w, h, seed=5)
+    st.submit_picture(w, h, imbs, ico, h263mi.PICTURE_I, temporal_reference=7)
+    rc, ref = orc.decode_picture(w, h, imbs, ico, None)
+    for f in range(4):
+        mbs, co = recgen.inter_picture(w, h, seed=30 + f, mv_range=60, p_4v=0.5, p_coded=0.5, quant=11)
+        st.submit_picture(w, h, mbs, co, h263mi.PICTURE_P, temporal_reference=7)
+        rc, ref = orc.decode_picture(w, h, mbs, co, ref)
+        pic = st.get_last_picture()
+        assert pic.temporal_reference == 7
+        assert_planes_equal(pic.as_yuv(), ref, "P%d with equal TR" % f)
+    st.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# batch error semantics (state.rs:142, 464-487: an error leaves the state unchanged)
+# ---------------------------------------------------------------------------------------------
+def _upload(arr):
+    d = h263mi.DeviceBuffer(max(arr.nbytes, 16))
+    if arr.nbytes:
+        d.upload(arr)
+    return d
+
+
+def test_batch_device_error_restores_the_previous_picture():
+    w, h = 64, 48
+    n_mb = 12
+    b = h263mi.Batch(1, w, h)
+    # first picture rejected by the device: no picture exists afterwards
+    pm, pc = recgen.inter_picture(w, h, seed=1, p_coded=0.5)
+    d_pm, d_pc = _upload(pm), _upload(pc)
+    b.decode(h263mi.PICTURE_P, d_pm.ptr, d_pc.ptr, None, len(pc))
+    with pytest.raises(h263mi.H263Error) as e:
+        b.sync()
+    assert e.value.code == h263mi.ERR_UNCODED_IFRAME_BLOCKS
+    with pytest.raises(h263mi.H263Error) as e:
+        b.copy_yuv(0)
+    assert e.value.code == h263mi.ERR_NO_PICTURE
+    # a good I picture, then a P picture with a coded block outside the pool: the I picture stays the last picture
+    im, ic = recgen.intra_picture(w, h, seed=2)
+    d_im, d_ic = _upload(im), _upload(ic)
+    b.decode(h263mi.PICTURE_I, d_im.ptr, d_ic.ptr, None, len(ic))
+    b.sync()
+    rc, ref = orc.decode_picture(w, h, im, ic, None)
+    assert_planes_equal(b.copy_yuv(0), ref, "I")
+    bad = pm.copy()
+    bad[5]["cbp"] = 0x3F
+    bad[5]["coeff_index"] = len(pc) - 2                         # blocks len-2 .. len+3: four of them outside
+    d_bad = _upload(bad)
+    b.decode(h263mi.PICTURE_P, d_bad.ptr, d_pc.ptr, None, len(pc))
+    with pytest.raises(h263mi.H263Error) as e:
+        b.sync()
+    assert e.value.code == h263mi.ERR_INVALID_ARGUMENT
+    assert_planes_equal(b.copy_yuv(0), ref, "after the rejected P picture")
+    # and it is still the reference: the valid P picture decodes from it
+    b.decode(h263mi.PICTURE_P, d_pm.ptr, d_pc.ptr, None, len(pc))
+    b.sync()
+    rc, want = orc.decode_picture(w, h, pm, pc, ref)
+    assert_planes_equal(b.copy_yuv(0), want, "P after the rejected one")
+    # two pictures in flight when the error surfaces: nothing survives
+    b.decode(h263mi.PICTURE_P, d_bad.ptr, d_pc.ptr, None, len(pc))
+    b.decode(h263mi.PICTURE_P, d_pm.ptr, d_pc.ptr, None, len(pc))
+    with pytest.raises(h263mi.H263Error):
+        b.sync()
+    with pytest.raises(h263mi.H263Error) as e:
+        b.copy_yuv(0)
+    assert e.value.code == h263mi.ERR_NO_PICTURE
+    b.sync()                                                     # the error has been consumed
+    b.close()
+    assert n_mb == len(pm)
+
+
+def test_batch_submit_host_validates_records():
+    w, h, n = 64, 48, 2
+    b = h263mi.Batch(n, w, h)
+    ims = [recgen.intra_picture(w, h, seed=s) for s in range(n)]
+    b.submit_host(h263mi.PICTURE_I, [m for m, c in ims], [c for m, c in ims])
+    b.sync()
+    before = [b.copy_yuv(s) for s in range(n)]
+    pms = [recgen.inter_picture(w, h, seed=10 + s, p_coded=0.5) for s in range(n)]
+    for field, value in (("coeff_index", 10 ** 6), ("quant", 0), ("mb_type", 9), ("cbp", 0x7F)):
+        bad = pms[1][0].copy()
+        bad[3][field] = value
+        if field == "coeff_index":
+            bad[3]["cbp"] = 1
+        with pytest.raises(h263mi.H263Error) as e:
+            b.submit_host(h263mi.PICTURE_P, [pms[0][0], bad], [pms[0][1], pms[1][1]])
+        assert e.value.code == h263mi.ERR_INVALID_ARGUMENT, field
+    b.sync()
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), before[s], "after rejected host submits")
+    # a picture without a single coded block, but a record that claims one: rejected too (pool size 0 is a bound)
+    empty = pms[0][0].copy()
+    empty["cbp"] = 0
+    empty["mb_type"] = 0
+    liar = empty.copy()
+    liar[2]["cbp"] = 4
+    with pytest.raises(h263mi.H263Error):
+        b.submit_host(h263mi.PICTURE_P, [empty, liar], [np.zeros((0, 64), np.int16)] * 2)
+    b.close()
+
+
+def test_state_ignores_the_batch_only_overlap_flag():
+    """a state created with H263MI_CFG_OVERLAP_POST must not race its RGBA copy against k_post"""
+    w, h = 352, 288
+    st = h263mi.H263State(cfg_flags=1)
+    mbs, co = recgen.intra_picture(w, h, seed=9)
+    cw = (w + 1) // 2
+    for rep in range(5):
+        st.submit_picture(w, h, mbs, co, h263mi.PICTURE_I)
+        rc, want = orc.decode_picture(w, h, mbs, co, None)
+        filt = tuple(orc.deblock(p, pw, 7) for p, pw in zip(want, (w, cw, cw)))
+        assert (st.render_rgba(7) == orc.yuv420_to_rgba(*filt, w)).all()
+    st.close()
+
+
+def test_probe_bandwidth_reports_a_plausible_ceiling():
+    copy = h263mi.probe_bandwidth(h263mi.PROBE_COPY, 256 << 20, 5)
+    read = h263mi.probe_bandwidth(h263mi.PROBE_READ, 256 << 20, 5)
+    write = h263mi.probe_bandwidth(h263mi.PROBE_WRITE, 256 << 20, 5)
+    for v in (copy, read, write):
+        assert 500.0 < v < 20000.0, (copy, read, write)

@@ -16,88 +16,101 @@ import sorenson_enc as enc
 from oracle import oracle as orc
 from test_bitstream_e2e import make_codable
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
-t_end = time.time() + budget
-n_pic = n_px = 0
-while time.time() < t_end:
-    w = int(rng.choice([rng.integers(1, 64), rng.integers(1, 420), 16 * rng.integers(1, 30), 176, 352]))
-    h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288]))
-    if rng.random() < 0.35:
-        # through the bitstream: records -> test encoder -> h263mi_decode_next_picture (host parser, sparse transport)
-        standard = bool(rng.integers(0, 2))
-        if standard:
-            w, h = [(128, 96), (176, 144), (352, 288), (4 * int(rng.integers(4, 60)), 4 * int(rng.integers(4, 40)))][int(rng.integers(0, 4))]
-        else:
-            w, h = min(w, 255), min(h, 255)
-        st = h263mi.H263State(0 if standard else h263mi.SORENSON_SPARK_BITSTREAM)
-        std = None
-        if standard:
-            std = {} if (w, h) in enc.STD_FORMATS and rng.random() < 0.5 else {"plus": True}
-        ref = None
-        for f in range(int(rng.integers(1, 4))):
-            s = int(rng.integers(0, 1 << 30))
-            q = int(rng.integers(1, 32))
-            lvl = 127 if standard else int(rng.choice([60, 1023]))
-            if f == 0:
-                mbs, co = recgen.intra_picture(w, h, seed=s, max_level=lvl)
-                mbs = make_codable(mbs, q, s, 0)
-                pt = 0
+
+class FuzzMismatch(AssertionError):
+    pass
+
+
+def run(budget=60.0, seed=1, verbose=True):
+    """random pictures for `budget` seconds; returns (pictures, pixels); raises FuzzMismatch on the first difference"""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n_pic = n_px = 0
+    while time.time() < t_end:
+        w = int(rng.choice([rng.integers(1, 64), rng.integers(1, 420), 16 * rng.integers(1, 30), 176, 352]))
+        h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288]))
+        if rng.random() < 0.35:
+            # through the bitstream: records -> test encoder -> h263mi_decode_next_picture (host parser, sparse transport)
+            standard = bool(rng.integers(0, 2))
+            if standard:
+                w, h = [(128, 96), (176, 144), (352, 288), (4 * int(rng.integers(4, 60)), 4 * int(rng.integers(4, 40)))][int(rng.integers(0, 4))]
             else:
-                mbs, co = recgen.inter_picture(w, h, seed=s, mv_range=32, p_coded=float(rng.choice([0.1, 0.5])),
-                                               p_4v=float(rng.choice([0.0, 0.4])), p_intra=0.1, quant=q, max_level=lvl,
-                                               sparse_low=bool(rng.integers(0, 2)))
-                mbs = make_codable(mbs, q, s, 1)
-                pt = 1
-            try:
-                data = enc.encode_picture(w, h, pt, q, mbs, co, temporal_reference=f, standard=std)
-            except (AssertionError, KeyError) as e:      # a record mix the little test encoder cannot express
-                print("encoder skipped:", w, h, pt, q, s, lvl, standard, repr(e)[:80])
-                break
-            st.decode_next_picture(data)
-            rc, ref = orc.decode_picture(w, h, mbs, co, ref if pt else None)
+                w, h = min(w, 255), min(h, 255)
+            st = h263mi.H263State(0 if standard else h263mi.SORENSON_SPARK_BITSTREAM)
+            std = None
+            if standard:
+                std = {} if (w, h) in enc.STD_FORMATS and rng.random() < 0.5 else {"plus": True}
+            ref = None
+            for f in range(int(rng.integers(1, 4))):
+                s = int(rng.integers(0, 1 << 30))
+                q = int(rng.integers(1, 32))
+                lvl = 127 if standard else int(rng.choice([60, 1023]))
+                if f == 0:
+                    mbs, co = recgen.intra_picture(w, h, seed=s, max_level=lvl)
+                    mbs = make_codable(mbs, q, s, 0)
+                    pt = 0
+                else:
+                    mbs, co = recgen.inter_picture(w, h, seed=s, mv_range=32, p_coded=float(rng.choice([0.1, 0.5])),
+                                                   p_4v=float(rng.choice([0.0, 0.4])), p_intra=0.1, quant=q, max_level=lvl,
+                                                   sparse_low=bool(rng.integers(0, 2)))
+                    mbs = make_codable(mbs, q, s, 1)
+                    pt = 1
+                try:
+                    data = enc.encode_picture(w, h, pt, q, mbs, co, temporal_reference=f, standard=std)
+                except (AssertionError, KeyError) as e:      # a record mix the little test encoder cannot express
+                    if verbose:
+                        print("encoder skipped:", w, h, pt, q, s, lvl, standard, repr(e)[:80])
+                    break
+                st.decode_next_picture(data)
+                rc, ref = orc.decode_picture(w, h, mbs, co, ref if pt else None)
+                assert rc == 0
+                for g, e, name in zip(st.get_last_picture().as_yuv(), ref, "Y Cb Cr".split()):
+                    if not (np.asarray(g) == e).all():
+                        raise FuzzMismatch("bitstream path: %r" % ((w, h, f, s, name, standard, seed),))
+                n_pic += 1
+                n_px += w * h
+            st.close()
+            continue
+        st = h263mi.H263State()
+        ref = None
+        for f in range(int(rng.integers(1, 5))):
+            s = int(rng.integers(0, 1 << 30))
+            if f == 0 or rng.random() < 0.15:
+                mbs, co = recgen.intra_picture(w, h, seed=s, max_level=int(rng.choice([3, 40, 127, 1023])))
+                pt = h263mi.PICTURE_I
+                want_ref = None
+            else:
+                mbs, co = recgen.inter_picture(w, h, seed=s, mv_range=int(rng.choice([2, 32, 70, 300])),
+                                               p_coded=float(rng.choice([0.05, 0.3, 0.9])), p_4v=float(rng.choice([0.0, 0.3, 1.0])),
+                                               p_intra=float(rng.choice([0.0, 0.2])), quant=int(rng.choice([0, 1, 10, 31])),
+                                               max_level=int(rng.choice([3, 60, 1023])), sparse_low=bool(rng.integers(0, 2)))
+                pt = h263mi.PICTURE_P
+                want_ref = ref
+            if want_ref is not None and rng.random() < 0.2 and len(mbs) > 2:     # a picture that ends early (padded as inter)
+                mbs = mbs[:int(rng.integers(1, len(mbs)))]
+            st.submit_picture(w, h, mbs, co, pt, temporal_reference=f)
+            rc, ref = orc.decode_picture(w, h, mbs, co, want_ref)
             assert rc == 0
-            for g, e, name in zip(st.get_last_picture().as_yuv(), ref, "Y Cb Cr".split()):
+            got = st.get_last_picture().as_yuv()
+            for g, e, name in zip(got, ref, "Y Cb Cr".split()):
                 if not (np.asarray(g) == e).all():
-                    print("MISMATCH bitstream", w, h, f, s, name, standard)
-                    sys.exit(1)
+                    raise FuzzMismatch("recon: %r" % ((w, h, f, s, name, seed),))
+            strength = int(rng.integers(0, 13))
+            cw = (w + 1) // 2
+            planes = ref if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(ref, (w, cw, cw)))
+            if not (st.render_rgba(strength) == orc.yuv420_to_rgba(*planes, w)).all():
+                raise FuzzMismatch("rgba: %r" % ((w, h, f, s, strength, seed),))
             n_pic += 1
             n_px += w * h
         st.close()
-        continue
-    st = h263mi.H263State()
-    ref = None
-    for f in range(int(rng.integers(1, 5))):
-        s = int(rng.integers(0, 1 << 30))
-        if f == 0 or rng.random() < 0.15:
-            mbs, co = recgen.intra_picture(w, h, seed=s, max_level=int(rng.choice([3, 40, 127, 1023])))
-            pt = h263mi.PICTURE_I
-            want_ref = None
-        else:
-            mbs, co = recgen.inter_picture(w, h, seed=s, mv_range=int(rng.choice([2, 32, 70, 300])),
-                                           p_coded=float(rng.choice([0.05, 0.3, 0.9])), p_4v=float(rng.choice([0.0, 0.3, 1.0])),
-                                           p_intra=float(rng.choice([0.0, 0.2])), quant=int(rng.choice([0, 1, 10, 31])),
-                                           max_level=int(rng.choice([3, 60, 1023])), sparse_low=bool(rng.integers(0, 2)))
-            pt = h263mi.PICTURE_P
-            want_ref = ref
-        if want_ref is not None and rng.random() < 0.2 and len(mbs) > 2:     # a picture that ends early (padded as inter)
-            mbs = mbs[:int(rng.integers(1, len(mbs)))]
-        st.submit_picture(w, h, mbs, co, pt, temporal_reference=f)
-        rc, ref = orc.decode_picture(w, h, mbs, co, want_ref)
-        assert rc == 0
-        got = st.get_last_picture().as_yuv()
-        for g, e, name in zip(got, ref, "Y Cb Cr".split()):
-            if not (np.asarray(g) == e).all():
-                print("MISMATCH recon", w, h, f, s, name)
-                sys.exit(1)
-        strength = int(rng.integers(0, 13))
-        cw = (w + 1) // 2
-        planes = ref if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(ref, (w, cw, cw)))
-        if not (st.render_rgba(strength) == orc.yuv420_to_rgba(*planes, w)).all():
-            print("MISMATCH rgba", w, h, f, s, strength)
-            sys.exit(1)
-        n_pic += 1
-        n_px += w * h
-    st.close()
-print("fuzz ok: %d pictures, %.1f MP, seed %d, %.0f s" % (n_pic, n_px / 1e6, seed, budget))
+    if verbose:
+        print("fuzz ok: %d pictures, %.1f MP, seed %d, %.0f s" % (n_pic, n_px / 1e6, seed, budget))
+    return n_pic, n_px
+
+
+if __name__ == "__main__":
+    try:
+        run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    except FuzzMismatch as e:
+        print("MISMATCH", e)
+        sys.exit(1)

@@ -1,13 +1,13 @@
 #!/bin/bash
-# PMC passes over a short bench run (each group in its own rocprofv3 run, counters only).
-# usage (on the GPU box, from the repo root): bash tools/prof_pmc.sh <tag> [bench args...]
+# PMC passes over a short bench run (each group in its own rocprofv3 run, counters only: never combined with
+# tracing).  usage (on the GPU box, from the repo root): bash tools/prof_pmc.sh <tag> [bench args...]
 set -u
 TAG=${1:-pmc}; shift || true
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="${@:---steps 8 --warmup 31 --no-cpu-baseline --no-extra}"
+ARGS="${@:---gops-per-step 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-parity-gate}"
 i=0
 while read -r GROUP; do
   [ -z "$GROUP" ] && continue
@@ -15,13 +15,16 @@ while read -r GROUP; do
   timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d $OUT/g$i -- python3 $R/bench.py $ARGS > $OUT/g$i.log 2>&1
   echo "group $i ($GROUP): rc=$?" >> $OUT/summary.txt
 done <<'GROUPS'
-FETCH_SIZE
-WRITE_SIZE
 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
-SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU
 TCC_HIT_sum TCC_MISS_sum
 TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+VALUBusy SALUBusy
+MemUnitBusy MemUnitStalled
+VALUUtilization OccupancyPercent
+TA_BUSY_avr TA_TA_BUSY_sum
+TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum
 GROUPS
 cd $R
 python3 tools/pmc_summary.py $OUT > $OUT/summary_table.txt 2>&1

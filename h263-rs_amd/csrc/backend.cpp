@@ -585,8 +585,9 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
             for (uint32_t k = 0; k < n_mbs[i]; k++) {                   // the same checks as h263mi_submit_picture
                 const MbRecord &m = mbs[i][k];
+                // (a record without coded blocks does not use its coeff_index)
                 if (m.mb_type > H263MI_MB_INTER4V_Q || m.quant < 1 || m.quant > 31 || (m.cbp & 0xC0) || (m.kill & 0xC0) ||
-                    (uint64_t)m.coeff_index + (uint64_t)__builtin_popcount(m.cbp) > n_coeff_blocks[i])
+                    (m.cbp && (uint64_t)m.coeff_index + (uint64_t)__builtin_popcount(m.cbp) > n_coeff_blocks[i]))
                     records_ok.store(false, std::memory_order_relaxed);
             }
             if (n_mbs[i]) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
@@ -793,7 +794,8 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
         if (m.mb_type > H263MI_MB_INTER4V_Q || m.quant < 1 || m.quant > 31 || (m.cbp & 0xC0) || (m.kill & 0xC0))
             return H263MI_ERR_INVALID_ARGUMENT;
         if (mb_is_inter(m.mb_type)) any_inter = true;
-        if ((size_t)m.coeff_index + (size_t)__builtin_popcount(m.cbp) > n_coeff_blocks) return H263MI_ERR_INVALID_ARGUMENT;
+        // (a record without coded blocks does not use its coeff_index)
+        if (m.cbp && (size_t)m.coeff_index + (size_t)__builtin_popcount(m.cbp) > n_coeff_blocks) return H263MI_ERR_INVALID_ARGUMENT;
     }
     const bool same_size = s->b && s->b->L.width == L.width && s->b->L.height == L.height;
     const bool has_ref = s->b && s->b->has_ref && s->b->cur >= 0;

@@ -11,6 +11,7 @@
  * Only bench.py's cpu_baseline leg (through oracle/native_bench.py) and tests/ use this file.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <malloc.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -110,6 +111,14 @@ double orc_bench_streams(int n_threads, int n_gops, int n_frames, uint16_t w, ui
                          const orc_bench_picture *pics, int n_distinct, uint8_t strength, uint64_t *checksums)
 {
     if (n_threads < 1 || n_gops < 1 || n_frames < 1 || n_distinct < 1 || !pics || !w || !h) return -100.0;
+    /* Like the reference (state.rs:179-191), the oracle allocates its per-picture block arrays anew for every picture
+     * (about 13 MB at 1080p).  With glibc's defaults each of those is an mmap + page-fault storm + munmap, and with one
+     * stream per core the process-wide mmap lock, not the decoder, sets the pace (measured: 8 % parallel
+     * efficiency on 128 cores).  Keep big blocks in the per-thread arenas instead, as a production build of the
+     * reference would with a pooling allocator. */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);      /* glibc's upper limit for this parameter */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
     pthread_barrier_t start, stop;
     if (pthread_barrier_init(&start, NULL, (unsigned)n_threads + 1)) return -1.0;
     if (pthread_barrier_init(&stop, NULL, (unsigned)n_threads + 1)) return -1.0;

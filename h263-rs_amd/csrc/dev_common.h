@@ -8,6 +8,7 @@
 // CPU test-suite only; it is not a product path.
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -26,6 +27,19 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 #endif
 
 namespace h263mi {
+
+// Hand-offs between the lanes of ONE wave go through LDS without a workgroup barrier: the DS operations of a wave
+// execute in order.  What still has to be said is that the COMPILER may not move a lane's LDS load above an earlier
+// store of another lane's data (or a store below a load): a release / acquire fence pair at wavefront scope with a
+// wave barrier in between orders them and emits no instruction.
+H263_DEV void wave_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // Frame layout in HBM.  One frame = Y plane, then Cb, then Cr, each PITCHED and

@@ -85,9 +85,14 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
         asm volatile("" : "+v"(ln));
         WaveMasks km;
         km.valid = recon_valid_mask(a, p);
-        km.act = km.inter = 0;
-        recon_phase_mark(a, s, ln, p, km);
-        recon_phase_compact(a, s, ln, km);
+        wave_fence();                               // the records are in LDS
+        const TaskInfo ti = recon_phase_mark(a, s, ln, p, km.valid, recon_block_limit(a, p));
+        const uint64_t act64 = __ballot(ti.active), inter64 = __ballot(ti.inter);
+        km.act = (uint32_t)act64;                   // bits 0..23
+        km.inter = (uint32_t)(inter64 >> WAVE_TASKS) & 0xffu;
+        recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index) != 0);
+        recon_phase_compact(s, ln, ti, km.act);
+        wave_fence();                               // descriptors and chroma vectors are in LDS
         ISA_MARK("mark_end");
         PHASE_MARK(1);
         WaveFetch f;
@@ -105,13 +110,17 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
             // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
             const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
                                 (__ballot(ri.w[3] != 0) ? 8u : 0u);
-            const uint64_t rb = __ballot(recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm)));      // bit slot*8 + row
-            uint32_t rows_mask = (uint32_t)rb | (uint32_t)(rb >> 32);
+            wave_fence();                           // the column pass of the previous round has read tbuf
+            const RowClass rc = recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm));
+            const uint64_t rows_any = __ballot(rc.any), cols_any = __ballot(rc.beyond_first);      // bit slot*8 + row
+            uint32_t rows_mask = (uint32_t)rows_any | (uint32_t)(rows_any >> 32);
             rows_mask |= rows_mask >> 16;
             rows_mask |= rows_mask >> 8;
+            const bool any_special = __ballot(recon_block_is_special(ri, ln, rows_any, cols_any)) != 0;
             asm volatile("" : "+v"(ln));
+            wave_fence();                           // the row pass results are in LDS
             ISA_MARK("idct_rows_end");
-            recon_phase_idct_cols(a, s, ln, round, rows_from_mask(rows_mask & 0xffu), km);
+            recon_phase_idct_cols(s, ri, ln, rows_from_mask(rows_mask & 0xffu), rows_any, cols_any, any_special);
             ISA_MARK("idct_cols_end");
         }
         PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
         PHASE_MARK(4);                              // reference rows have arrived
 #endif
         asm volatile("" : "+v"(ln));
+        wave_fence();                               // the residual strip is complete
         ISA_MARK("output_begin");
         recon_phase_output(a, s, f, ln, p, km);
         ISA_MARK("output_end");
@@ -151,33 +161,41 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
 // neighbouring tiles at any moment: the cache lines that the 4-pixel tile offset makes two tiles
 // share are then fetched once per L2 instead of once per XCD.
 // ---------------------------------------------------------------------------------------
-// Two strips of a tile.  FETCH_AHEAD: queue the loads of the strips two further down right after each
-// commit, so that they are in flight while this pair is filtered and stored.
 template <bool FETCH_AHEAD>
-__device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s, PostFetch &pf0, PostFetch &pf1, int lane,
-                                                int sx, int sy, int pic)
+__device__ __forceinline__ void post_strip(const PostArgs &a, PostStrip &s, PostFetch &pf, int lane, int sx, int sy, int pic)
 {
     // `ln`: the lane index behind an opaque asm, re-derived per strip so that lane-only expressions (LDS
     // offsets, column indices, ...) are recomputed where used instead of being kept in registers across
     // the whole kernel -- the hoisted form cost half of the occupancy.
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    post_phase_commit(a, s, pf0, ln);
-    if (FETCH_AHEAD) post_phase_fetch(a, pf0, ln, sx, sy + 2, pic);
+    ISA_MARK("strip_begin");
+    wave_fence();                                   // the previous strip has been read out of LDS
+    post_phase_commit(a, s, pf, ln);
+    ISA_MARK("commit_end");
+    if (FETCH_AHEAD) post_phase_fetch(a, pf, ln, sx, sy + 2, pic);
+    ISA_MARK("fetch_end");
+    wave_fence();                                   // the strip is in LDS
     if (a.strength) {
         post_phase_hedges(a, s, ln, sx, sy);
+        wave_fence();
+        ISA_MARK("hedges_end");
         post_phase_vedges(a, s, ln, sx, sy);
+        wave_fence();
+        ISA_MARK("vedges_end");
     }
     post_phase_store(a, s, ln, sx, sy, pic);
+    ISA_MARK("store_end");
+}
 
-    asm volatile("" : "+v"(ln));
-    post_phase_commit(a, s, pf1, ln);
-    if (FETCH_AHEAD) post_phase_fetch(a, pf1, ln, sx, sy + 3, pic);
-    if (a.strength) {
-        post_phase_hedges(a, s, ln, sx, sy + 1);
-        post_phase_vedges(a, s, ln, sx, sy + 1);
-    }
-    post_phase_store(a, s, ln, sx, sy + 1, pic);
+// Two strips of a tile.  FETCH_AHEAD: queue the loads of the strips two further down right after each
+// commit, so that they are in flight while this pair is filtered and stored.
+template <bool FETCH_AHEAD>
+__device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s, PostFetch &pf0, PostFetch &pf1, int lane,
+                                                int sx, int sy, int pic)
+{
+    post_strip<FETCH_AHEAD>(a, s, pf0, lane, sx, sy, pic);
+    post_strip<FETCH_AHEAD>(a, s, pf1, lane, sx, sy + 1, pic);
 }
 
 __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)

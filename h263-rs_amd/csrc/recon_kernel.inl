@@ -15,9 +15,13 @@
 // waves of an 8x2-macroblock tile, and neighbouring tiles, on one L2.
 //
 // Wave timeline:
-//   records  : 8 records (256 B) -> LDS; list of blocks that need an IDCT (coded & !kill, or
-//              uncoded intra with non-zero DC) compacted in LDS; chroma vectors and the mask
-//              of inter macroblocks once per MB
+//   records  : 8 records (256 B) -> LDS
+//   mark     : lane t < 24 = block task t: decides whether the block goes through the IDCT (coded & !kill, or
+//              uncoded intra with non-zero DC) and builds its 8-byte DESCRIPTOR (where its coefficients are,
+//              quantiser, INTRADC level, intra flag, task number); lanes 24..31 = the 8 macroblocks: chroma vector
+//              (packed 16-bit arithmetic) and the inter flag.  The wave-wide masks are ballots (scalar registers);
+//              the descriptors of the active tasks are compacted in LDS -- every later phase reads a descriptor
+//              instead of walking list -> record -> cbp -> popcount -> coeff_index again
 //   fetch    : ALL global loads are issued now, before any arithmetic: the reference rows of
 //              the lane's three segments (one dword-aligned 12-byte load per row; rows nobody
 //              needs read offset 0; picture-edge segments load the window that holds all their
@@ -25,9 +29,10 @@
 //   idct     : rounds of 8 blocks, 8 lanes per block, lane = one coefficient row: dequant (packed i16),
 //              row pass T = C x B -> LDS; then lane = one pixel column: column of T (the
 //              LDS transposition), column pass, rounding -> residual strip (i16) in LDS; both
-//              passes stop at the last non-zero coefficient column / row of the round
+//              passes stop at the last non-zero coefficient column / row of the round; the block classes
+//              (rle.rs:138-170) come out of two ballots
 //   output   : lane = 8 horizontal pixels: one branch-free half-pel form on packed bytes, + residual
-//              row (packed i16 add, saturate to u8), one 8-byte store
+//              row (packed i16 add, saturating pack to u8), one 8-byte store
 //
 // Bit-exactness rules: f32 multiply and add are separately rounded
 // (translation unit built with -ffp-contract=off), accumulation order over the
@@ -56,13 +61,30 @@ constexpr int TBUF_STRIDE = 8 * TBUF_ROW;      // 72 floats per slot: column rea
 constexpr int RES_STRIDE = 192;                // residual strip row: 128 luma + 64 chroma columns
 
 struct ReconWave {
-    MbRecord rec[TILE_MBX];                    // 256 B
-    int16_t  mvc[TILE_MBX][2];                 // chroma vector per macroblock (gather.rs:182)
-    uint8_t  list[WAVE_TASKS];                 // compacted active tasks
+    uint32_t rec[TILE_MBX][8];                 // the 8 records as dwords: [0] mb_type | quant << 8 | cbp << 16 | kill << 24,
+                                               // [1..4] the four vectors (x | y << 16), [5] intradc 0..3, [6] intradc 4..5, [7] coeff_index
+    uint32_t mvc[TILE_MBX];                    // chroma vector per macroblock, x | y << 16 (gather.rs:182)
+    uint32_t desc[WAVE_TASKS][2];              // descriptors of the active tasks, compacted (see TaskInfo)
     float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results; column 8 of each row keeps C[r][0] for the Vert class
-    uint8_t  flags[ROUND_BLOCKS * 8];
     int16_t  res[8 * RES_STRIDE];              // residual strip: 8 rows x (128 luma | 64 chroma) columns
 };
+static_assert(sizeof(MbRecord) == 32 && offsetof(MbRecord, mv) == 4 && offsetof(MbRecord, intradc) == 20 &&
+              offsetof(MbRecord, coeff_index) == 28, "record words used by the mark phase");
+
+// What the mark phase knows about a block task.  d0: byte offset of the block's 64 LEVELs from the picture's first
+// coefficient block, or NO_COEFFS when the block has no TCOEF (or lies outside the pool).  d1: quant | INTRADC level
+// << 8 | intra << 19 | task << 20.
+constexpr uint32_t NO_COEFFS = 0xffffffffu;
+struct TaskInfo {
+    uint32_t d0, d1;
+    bool active;                               // the block goes through the IDCT
+    bool inter;                                // (macroblock lanes) inside the picture and inter coded
+    bool bad_index;                            // coded block outside the coefficient pool
+};
+H263_HD uint32_t desc_quant(uint32_t d1) { return d1 & 0xffu; }
+H263_HD uint32_t desc_level(uint32_t d1) { return (d1 >> 8) & 0x7ffu; }
+H263_HD bool     desc_intra(uint32_t d1) { return (d1 >> 19) & 1u; }
+H263_HD int      desc_task(uint32_t d1) { return (int)(d1 >> 20); }
 
 // Wave-wide bit masks.  On the device they come out of ballots and live in scalar registers; the CPU logic checker
 // (tests/sim) runs the lanes one after the other and ORs the lanes' bits together.
@@ -86,6 +108,8 @@ H263_HD int popc32(uint32_t v)
     return __builtin_popcount(v);
 #endif
 }
+
+H263_HD int recon_n_active(const WaveMasks &k) { return popc32(k.act); }
 
 // block task t of a wave -> (macroblock 0..7, block 0..5)
 H263_HD int task_mb(int t) { return t < 16 ? (t >> 1) : (t - 16); }
@@ -165,23 +189,52 @@ H263_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 #endif
 }
 
+// packed 16-bit integer helpers (both halves of a dword at once; wrapping like the reference's i16 arithmetic)
+H263_DEV uint32_t pk_add_u16(uint32_t x, uint32_t y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return ((x + y) & 0xffffu) | (((x >> 16) + (y >> 16)) << 16);
+#endif
+}
+H263_DEV uint32_t pk_ashr_i16(uint32_t x, uint32_t n)          // arithmetic shift right of both halves by the constant n
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "n"(n), "v"(x));
+    return r;
+#else
+    const uint32_t lo = (uint32_t)((int16_t)(x & 0xffffu) >> n) & 0xffffu, hi = (uint32_t)((int16_t)(x >> 16) >> n) & 0xffffu;
+    return lo | (hi << 16);
+#endif
+}
+H263_DEV uint32_t pk_lshl_u16(uint32_t x, uint32_t n)          // shift left of both halves by the constant n
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "n"(n), "v"(x));
+    return r;
+#else
+    return ((x << n) & 0xffffu) | (((x >> 16) << n) << 16);
+#endif
+}
+
 // four prediction bytes + four i16 residuals (two dwords) -> four clipped bytes
 // (clipped_idct + mocomp_pixel).clamp(0, 255)  idct.rs:127-130, 191-194
 H263_DEV uint32_t add_clip_u8x4(uint32_t pred, uint32_t r01, uint32_t r23)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef short short2v __attribute__((ext_vector_type(2)));
-    union U { uint32_t u; short2v v; };
-    U p01, p23, a, b;
-    p01.u = __builtin_amdgcn_perm(0u, pred, 0x0c010c00u);       // (p0, p1) as i16
-    p23.u = __builtin_amdgcn_perm(0u, pred, 0x0c030c02u);       // (p2, p3)
-    a.u = r01;
-    b.u = r23;
-    const short2v zero = {0, 0}, top = {255, 255};
-    U s01, s23;
-    s01.v = __builtin_elementwise_min(__builtin_elementwise_max(p01.v + a.v, zero), top);
-    s23.v = __builtin_elementwise_min(__builtin_elementwise_max(p23.v + b.v, zero), top);
-    return __builtin_amdgcn_perm(s23.u, s01.u, 0x06040200u);    // low bytes of the four lanes
+    const uint32_t p01 = __builtin_amdgcn_perm(0u, pred, 0x0c010c00u);       // (p0, p1) as i16
+    const uint32_t p23 = __builtin_amdgcn_perm(0u, pred, 0x0c030c02u);       // (p2, p3)
+    // v_sat_pk_u8_i16: both halves saturated to 0..255 and packed into bits 15:0 (what it leaves in bits 31:16 is
+    // not relied upon: the permute below picks bytes 0 and 1 of each)
+    uint32_t b01, b23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(pk_add_u16(p01, r01)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(pk_add_u16(p23, r23)));
+    return __builtin_amdgcn_perm(b23, b01, 0x05040100u);
 #else
     uint32_t out = 0;
     const uint32_t r[2] = {r01, r23};
@@ -308,6 +361,18 @@ H263_DEV uint32_t recon_valid_mask(const ReconArgs &a, const WavePos &p)
     return (p.mby < (int)a.L.mbh && n > 0) ? (n >= TILE_MBX ? 0xffu : (1u << n) - 1u) : 0u;
 }
 
+// Coded blocks this wave may address: the pool holds a.coeff_pool_blocks blocks (when the caller told us), the
+// picture's first block is p.cbase, and block offsets are 32-bit byte offsets (2^25 blocks of 128 bytes).
+H263_DEV uint32_t recon_block_limit(const ReconArgs &a, const WavePos &p)
+{
+    uint64_t lim = 1u << 25;
+    if (a.coeff_checked) {
+        const uint64_t left = a.coeff_pool_blocks > p.cbase ? a.coeff_pool_blocks - p.cbase : 0;
+        if (left < lim) lim = left;
+    }
+    return (uint32_t)lim;
+}
+
 H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p)
 {
     if (lane < TILE_MBX * 2) {
@@ -319,63 +384,76 @@ H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const
             const MbRecord *r = a.mbs + (size_t)p.pic * a.mbs_per_picture + (size_t)p.mby * a.L.mbw + mbx;
             v = reinterpret_cast<const uint4 *>(r)[part];
         }
-        reinterpret_cast<uint4 *>(&s.rec[m])[part] = v;
+        reinterpret_cast<uint4 *>(&s.rec[m][0])[part] = v;
     }
 }
 
-// ---- phase 1: which blocks need the IDCT; chroma vectors -------------------------------
-// Straight-line: every lane reads the record words it might need in one go (one wait), the decisions are
-// plain arithmetic, and the two masks are ballots over the whole wave.  `k` masks must arrive with valid set and
-// act = inter = 0.
-H263_DEV void recon_phase_mark(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, WaveMasks &k)
+// ---- phase 1: which blocks need the IDCT, their descriptors; chroma vectors -------------------------------
+// Straight-line and branch-free: every lane reads the eight words of "its" record (four two-dword LDS reads from one
+// address register), the decisions are plain arithmetic.  Lanes 0..23 are block task `lane`, lanes 24..31 macroblock
+// lane - 24; the other lanes compute along and are ignored.
+H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, const WavePos &p, uint32_t valid_mask,
+                                   uint32_t block_limit)
 {
-    // lanes 0..23: block task `lane`; lanes 24..31: macroblock lane - 24 (chroma vector, inter flag)
     const bool is_task = lane < WAVE_TASKS, is_mb = lane >= WAVE_TASKS && lane < WAVE_TASKS + TILE_MBX;
-    const int m = is_task ? task_mb(lane) : ((lane - WAVE_TASKS) & (TILE_MBX - 1));
-    const int blk = is_task ? task_blk(lane, p.half) : 0;
-    const MbRecord &r = s.rec[m];
-    uint32_t head;                                               // mb_type | quant << 8 | cbp << 16 | kill << 24
-    memcpy(&head, &r, 4);
-    const uint32_t dc = r.intradc[blk];
-    uint32_t mv[4];
-    memcpy(mv, &r.mv[0][0], 16);
-    const uint32_t mb_type = head & 0xffu, cbp = (head >> 16) & 0xffu, kill = head >> 24;
-    const bool valid = (k.valid >> m) & 1;
-    const bool coded = (cbp >> blk) & 1;
+    const int m = lane < 16 ? (lane >> 1) : (lane & 7);
+    const uint32_t blk = lane < 16 ? (uint32_t)(p.half * 2 + (lane & 1)) : (uint32_t)(4 + p.half);
+    const uint32_t *r = s.rec[m];
+    const uint32_t w0 = r[0], w7 = r[7], w5 = r[5], w6 = r[6], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4];
+
+    const uint32_t mb_type = w0 & 0xffu, cbpkill = w0 >> 16;
+    const bool valid = (valid_mask >> m) & 1u;
+    const bool intra = mb_type - 3u < 2u;                        // types.rs:661-663
+    const bool coded = (cbpkill >> blk) & 1u, killed = (cbpkill >> (8u + blk)) & 1u;
+    const uint32_t dcb = (uint32_t)((((uint64_t)w6 << 32) | w5) >> (8u * blk)) & 0xffu;
+    const uint32_t level = dcb == 0xffu ? 1024u : dcb << 3;     // IntraDc::into_level, types.rs:955-961
+    // number of this block among the macroblock's coded blocks -> its place in the pool
+    const uint32_t idx = w7 + (uint32_t)popc32(cbpkill & ((1u << blk) - 1u) & 0x3fu);
+    const bool in_range = w7 < block_limit && idx < block_limit;
+
+    TaskInfo t;
     // coded & kill -> Zero (rle.rs:125-127); uncoded inter -> Zero; uncoded intra -> Dc(level)
-    const bool active = is_task && valid &&
-                        (coded ? !((kill >> blk) & 1) : (mb_is_intra(mb_type) && intradc_level(dc) != 0));
-    // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
-    const bool inter = is_mb && valid && mb_is_inter(mb_type);
-#if defined(__HIP_DEVICE_COMPILE__)
-    k.act = (uint32_t)__ballot(active);
-    k.inter = (uint32_t)(__ballot(inter) >> WAVE_TASKS) & 0xffu;
-    if (k.inter && !a.has_ref && lane == 0) atomicOr(a.status, STATUS_INTER_WITHOUT_REFERENCE);   // Error::UncodedIFrameBlocks
-#else
-    if (active) k.act |= 1u << lane;
-    if (inter) {
-        k.inter |= 1u << m;
-        if (!a.has_ref) *a.status |= STATUS_INTER_WITHOUT_REFERENCE;
+    t.active = is_task && valid && (coded ? !killed : (intra && dcb != 0));
+    t.bad_index = t.active && coded && !in_range;
+    t.d0 = (coded && in_range) ? idx << 7 : NO_COEFFS;
+    t.d1 = ((w0 >> 8) & 0xffu) | (level << 8) | ((intra ? 1u : 0u) << 19) | ((uint32_t)lane << 20);
+    // which macroblocks take a prediction from the reference picture (gather.rs:136-149; types.rs:653-658)
+    t.inter = is_mb && valid && !intra && mb_type < 6u;
+
+    // gather.rs:182 / types.rs:759-768: chroma vector from the i16 sum of the four luma vectors, both components at
+    // once in the two halves of a dword.  s = sum, whole = (s >> 4) << 1, frac = s & 15,
+    // result = whole + (frac > 2) + (frac >= 14) = whole + ((frac + 13) >> 4) + ((frac + 2) >> 4)
+    {
+        const uint32_t sum = pk_add_u16(pk_add_u16(w1, w2), pk_add_u16(w3, w4));
+        const uint32_t whole = pk_lshl_u16(pk_ashr_i16(sum, 4), 1);
+        const uint32_t frac = sum & 0x000f000fu;
+        const uint32_t up = (((frac + 0x000d000du) >> 4) & 0x00010001u) + (((frac + 0x00020002u) >> 4) & 0x00010001u);
+        if (is_mb) s.mvc[m] = pk_add_u16(whole, up);
     }
-#endif
-    if (is_mb) {
-        // gather.rs:182: chroma vector from the i16 sum of the four luma vectors
-        const int sx = (int16_t)(mv[0] & 0xffffu) + (int16_t)(mv[1] & 0xffffu) + (int16_t)(mv[2] & 0xffffu) + (int16_t)(mv[3] & 0xffffu);
-        const int sy = (int16_t)(mv[0] >> 16) + (int16_t)(mv[1] >> 16) + (int16_t)(mv[2] >> 16) + (int16_t)(mv[3] >> 16);
-        s.mvc[m][0] = (int16_t)average_sum_of_mvs(sx);
-        s.mvc[m][1] = (int16_t)average_sum_of_mvs(sy);
-    }
+    return t;
 }
 
-// ---- phase 2: compact the active tasks ----------------------------------------------
-H263_DEV void recon_phase_compact(const ReconArgs &, ReconWave &s, int lane, const WaveMasks &k)
+// ---- phase 2: compact the descriptors of the active tasks ----------------------------------------------
+H263_DEV void recon_phase_compact(ReconWave &s, int lane, const TaskInfo &t, uint32_t act_mask)
 {
-    if (lane >= WAVE_TASKS) return;
-    if (!((k.act >> lane) & 1)) return;
-    s.list[popc32(k.act & ((1u << lane) - 1u))] = (uint8_t)lane;
+    if (!t.active) return;
+    uint32_t *d = s.desc[popc32(act_mask & ((1u << lane) - 1u))];
+    d[0] = t.d0;
+    d[1] = t.d1;
 }
 
-H263_DEV int recon_n_active(const WaveMasks &k) { return popc32(k.act); }
+// status bits of the wave (wave-uniform on the device: the caller passes ballots)
+H263_DEV void recon_report(const ReconArgs &a, int lane, bool inter_without_reference, bool bad_index)
+{
+    const uint32_t bits = (inter_without_reference ? STATUS_INTER_WITHOUT_REFERENCE : 0u) |    // Error::UncodedIFrameBlocks
+                          (bad_index ? STATUS_COEFF_INDEX_OUT_OF_RANGE : 0u);
+    if (!bits || lane != 0) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(a.status, bits);
+#else
+    *a.status |= bits;
+#endif
+}
 
 // ---- phase 3: issue every global load of the wave ------------------------------------------
 // One 8-pixel row segment of the lane: its motion vector and the raw reference bytes (12 per
@@ -390,7 +468,8 @@ struct WaveFetch {
                                // (0, 0) when the macroblock takes no prediction
     uint32_t flags;            // two bits per vector: SEG_INTER: motion compensated (else prediction = 0);
                                // SEG_BORDER: some tap falls outside the picture, redone with clamping
-    uint4    coef0;            // coefficient row of the first IDCT round
+    uint32_t d0, d1;           // descriptor of the lane's block in the first IDCT round
+    uint4    coef0;            // ... and its coefficient row
 };
 
 // segment k of a lane -> geometry.  Segments 0 and 1 are the same luma column, four rows apart.
@@ -477,6 +556,13 @@ H263_DEV void gather_row_clamped(uint32_t w[3], int u, int ub, int pw)
     w[0] = o0; w[1] = o1; w[2] = o2;
 }
 
+// coefficient row `r` of the block descriptor d0 describes (any mapped address when there is none)
+H263_DEV const uint8_t *coeff_row_address(const ReconArgs &a, const WavePos &p, uint32_t d0, bool wanted, int r)
+{
+    const uint8_t *pic = reinterpret_cast<const uint8_t *>(a.coeffs) + p.cbase * 128u;      // uniform
+    return (wanted && d0 != NO_COEFFS) ? pic + d0 + (uint32_t)r * 16u : reinterpret_cast<const uint8_t *>(a.mbs);
+}
+
 // The loads are issued unconditionally and in a fixed order -- coefficient row first, then two
 // 12-byte reference rows per segment -- so that the wait in front of the row pass can leave the six
 // reference loads in flight (s_waitcnt vmcnt(6)): the IDCT of this wave overlaps its own motion
@@ -487,20 +573,10 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
 {
     const uint8_t *ref = a.ref + (size_t)p.pic * a.L.frame_bytes;
     {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.mbs);      // dummy: any mapped address
         const int slot = lane >> 3, r = lane & 7;
-        if (slot < recon_n_active(km)) {
-            const int t = s.list[slot];
-            const int m = task_mb(t), blk = task_blk(t, p.half);
-            const MbRecord &rec = s.rec[m];
-            if ((rec.cbp >> blk) & 1) {
-                const uint64_t cidx = p.cbase + rec.coeff_index +
-                                      (uint64_t)popc32(rec.cbp & ((1u << blk) - 1u));
-                if (!(a.coeff_checked && cidx >= a.coeff_pool_blocks))
-                    src = reinterpret_cast<const uint8_t *>(a.coeffs + cidx * 64 + (size_t)r * 8);
-            }
-        }
-        f.coef0 = *reinterpret_cast<const uint4 *>(src);       // uncoded slots ignore it
+        f.d0 = s.desc[slot][0];                                // (garbage beyond the active tasks: never used)
+        f.d1 = s.desc[slot][1];
+        f.coef0 = *reinterpret_cast<const uint4 *>(coeff_row_address(a, p, f.d0, slot < recon_n_active(km), r));
     }
     // gather.rs:149: without a reference picture nothing is motion compensated (the error is already
     // in the status word)
@@ -511,9 +587,7 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
         SegFetch &sf = f.seg[k];
         const SegGeo g = seg_geometry(a, lane, k, p);
         const bool mc = (mc_mask >> g.m) & 1;
-        uint32_t mvw;                                   // (mvx, mvy) as one LDS word
-        if (g.luma) memcpy(&mvw, &s.rec[g.m].mv[g.blk][0], 4);
-        else memcpy(&mvw, &s.mvc[g.m][0], 4);
+        uint32_t mvw = g.luma ? s.rec[g.m][1 + g.blk] : s.mvc[g.m];     // (mvx, mvy) as one LDS word
         mvw = mc ? mvw : 0u;
         const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int16_t)(mvw >> 16);
         // HalfPel::into_lerp_parameters (types.rs:721-729): floor(mv / 2), odd -> interpolate
@@ -547,45 +621,27 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
 // ---- phase 4a: coefficient row of the lane, row pass -----------------------------------------
 struct RowIn {
     uint32_t w[4];             // the 8 LEVELs of the lane's coefficient row (zeros when the block has no TCOEF)
-    int16_t  quant, dc_level;  // dc_level: INTRADC level
-    uint8_t  active, use_dc;   // use_dc: intra block, row 0: the DC comes from INTRADC (rle.rs:117-121)
+    uint32_t d1;               // descriptor word 1 of the lane's block (quantiser, INTRADC level, intra, task)
+    bool     active;           // the lane's slot holds a block in this round
 };
 
 H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
                                     int round, RowIn &ri, const WaveMasks &km)
 {
-    ri.w[0] = ri.w[1] = ri.w[2] = ri.w[3] = 0;
-    ri.quant = 1; ri.dc_level = 0; ri.active = 0; ri.use_dc = 0;
     const int slot = lane >> 3, r = lane & 7;
     const int k = round * ROUND_BLOCKS + slot;
-    if (k >= recon_n_active(km)) return;
-    const int t = s.list[k];
-    const int m = task_mb(t), blk = task_blk(t, p.half);
-    const MbRecord &rec = s.rec[m];
-    ri.active = 1;
-    ri.quant = rec.quant;
-    ri.use_dc = mb_is_intra(rec.mb_type) && r == 0;
-    ri.dc_level = (int16_t)intradc_level(rec.intradc[blk]);
-    if ((rec.cbp >> blk) & 1) {
-        const uint64_t cidx = p.cbase + rec.coeff_index +
-                              (uint64_t)popc32(rec.cbp & ((1u << blk) - 1u));
-        if (a.coeff_checked && cidx >= a.coeff_pool_blocks) {
-            if (r == 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                atomicOr(a.status, STATUS_COEFF_INDEX_OUT_OF_RANGE);
-#else
-                *a.status |= STATUS_COEFF_INDEX_OUT_OF_RANGE;
-#endif
-            }
-        } else {
-            // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r);
-            // round 0 was loaded ahead of time by recon_phase_fetch
-            uint4 raw = f.coef0;
-            if (round > 0)
-                raw = *reinterpret_cast<const uint4 *>(a.coeffs + cidx * 64 + (size_t)r * 8);
-            ri.w[0] = raw.x; ri.w[1] = raw.y; ri.w[2] = raw.z; ri.w[3] = raw.w;
-        }
+    ri.active = k < recon_n_active(km);
+    uint32_t d0 = f.d0;
+    uint4 raw = f.coef0;                                        // round 0 was loaded ahead of time by recon_phase_fetch
+    ri.d1 = f.d1;
+    if (round > 0) {                                            // uniform
+        d0 = s.desc[k % WAVE_TASKS][0];
+        ri.d1 = s.desc[k % WAVE_TASKS][1];
+        // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r)
+        raw = *reinterpret_cast<const uint4 *>(coeff_row_address(a, p, d0, ri.active, r));
     }
+    const bool has = ri.active && d0 != NO_COEFFS;
+    ri.w[0] = has ? raw.x : 0u; ri.w[1] = has ? raw.y : 0u; ri.w[2] = has ? raw.z : 0u; ri.w[3] = has ? raw.w : 0u;
 }
 
 // lane's contribution to cols_from_mask
@@ -594,14 +650,23 @@ H263_DEV uint32_t rowin_word_mask(const RowIn &ri)
     return (ri.w[1] ? 2u : 0u) | (ri.w[2] ? 4u : 0u) | (ri.w[3] ? 8u : 0u);
 }
 
-// Returns whether the lane's coefficient row holds anything non-zero (the caller folds these into
-// rows_from_mask's argument: a ballot on the device).
-H263_DEV bool recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols)
+// What a lane's coefficient row contributes to the classification of its block (rle.rs:138-149): a non-zero value
+// with y > 0 breaks "horiz", one with x > 0 breaks "vert".  A LEVEL is non-zero exactly when its dequantised value
+// is (|v| >= 3q - 1), so this is decided on the raw words.
+struct RowClass {
+    bool any;                  // the row holds a non-zero coefficient
+    bool beyond_first;         // ... in a column x > 0
+};
+
+H263_DEV RowClass recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols)
 {
-    if (!ri.active) return false;
+    RowClass rc = {false, false};
+    if (!ri.active) return rc;
     const int slot = lane >> 3, r = lane & 7;
-    const uint32_t quant = (uint32_t)ri.quant;
-    const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = (quant - ((quant & 1u) ? 0u : 1u)) * 0x00010001u;
+    const uint32_t quant = desc_quant(ri.d1);
+    // 2q and q - (q even) = (q - 1) | 1 in both halves of a dword
+    const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = ((quant - 1u) | 1u) * 0x00010001u;
+    const bool use_dc = desc_intra(ri.d1) && r == 0;            // intra block: the DC comes from INTRADC (rle.rs:117-121)
 
     float C[8];
 #pragma unroll
@@ -613,15 +678,9 @@ H263_DEV bool recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
             C[2 * j + 1] = (float)((int)v >> 16);
         }
     }
-    if (ri.use_dc) C[0] = (float)ri.dc_level;
-
-    // classification inputs (rle.rs:138-149): a non-zero value with y > 0 breaks "horiz",
-    // one with x > 0 breaks "vert"
-    bool cols_nz = false;
-#pragma unroll
-    for (int c = 1; c < 8; c++) cols_nz = cols_nz || (C[c] != 0.0f);
-    const bool row_any = cols_nz || (C[0] != 0.0f);
-    s.flags[slot * 8 + r] = (uint8_t)(((row_any && r > 0) ? 1 : 0) | (cols_nz ? 2 : 0));
+    if (use_dc) C[0] = (float)(int)desc_level(ri.d1);
+    rc.beyond_first = ((ri.w[0] >> 16) | ri.w[1] | ri.w[2] | ri.w[3]) != 0;
+    rc.any = rc.beyond_first || (use_dc ? desc_level(ri.d1) != 0 : (ri.w[0] & 0xffffu) != 0);
 
     // idct_1d over the coefficient row (idct.rs:52-65)
     f32x2 T[4];
@@ -630,23 +689,21 @@ H263_DEV bool recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
 #pragma unroll
     for (int i = 0; i < 8; i++) dst[i] = T[i >> 1][i & 1];
     dst[8] = C[0];
-
-    return row_any;
+    return rc;
 }
 
 // ---- phase 4b: column pass, rounding, residual strip -------------------------------------
-H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, int round, int n_rows, const WaveMasks &km)
+// rows_any / cols_any: bit slot*8 + r set when coefficient row r of the slot's block holds a non-zero value /
+// one in a column x > 0 (ballots of RowClass on the device).  A block is Horiz when no row r > 0 holds anything,
+// Vert when no row holds anything beyond column 0, Dc (or Zero) when both (rle.rs:138-171).
+H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int n_rows, uint64_t rows_any, uint64_t cols_any,
+                                    bool any_special)
 {
+    if (!ri.active) return;
     const int slot = lane >> 3, i = lane & 7;
-    const int k = round * ROUND_BLOCKS + slot;
-    if (k >= recon_n_active(km)) return;
-    const int t = s.list[k];
-
-    uint64_t fl;
-    memcpy(&fl, &s.flags[slot * 8], 8);
-    const bool is_horiz = (fl & 0x0101010101010101ull) == 0;
-    const bool is_vert = (fl & 0x0202020202020202ull) == 0;
-    const float c00 = s.tbuf[slot * TBUF_STRIDE + 8];
+    const int t = desc_task(ri.d1);
+    const uint32_t slot_rows = (uint32_t)(rows_any >> (8 * slot)) & 0xfeu, slot_cols = (uint32_t)(cols_any >> (8 * slot)) & 0xffu;
+    const bool is_horiz = slot_rows == 0, is_vert = slot_cols == 0;
 
     // Vert (rle.rs:162-171, idct.rs:152-169) transforms the first column directly (kept in column 8
     // of the slot); every other class reads column i of the row-pass result (the transposition of
@@ -661,15 +718,20 @@ H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, i
     f32x2 O[4];
     const BasisPtr B = basis_table();
     idct_1d_pairs(B, col, O, n_rows);
-    // class fix-ups as one multiply and one add (both exact where they must not change the value):
-    //   Vert: x * B[0][0] (idct.rs:160)          others: x * 1.0
-    //   Dc  : x * 0 + dc * 0.5 (idct.rs:119: exactly 0.5, not B00*B00; dc = 0 gives the Zero class)
-    const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? B[0][0] : 1.0f));
-    const f32x2 shift = splat2(dc_class ? c00 * 0.5f : 0.0f);
+    if (any_special) {                                             // uniform: some block of the round is Vert, Dc or Zero
+        // class fix-ups as one multiply and one add (both exact where they must not change the value):
+        //   Vert: x * B[0][0] (idct.rs:160)          others: x * 1.0
+        //   Dc  : x * 0 + dc * 0.5 (idct.rs:119: exactly 0.5, not B00*B00; dc = 0 gives the Zero class)
+        const float c00 = s.tbuf[slot * TBUF_STRIDE + 8];
+        const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? B[0][0] : 1.0f));
+        const f32x2 shift = splat2(dc_class ? c00 * 0.5f : 0.0f);
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) O[jp] = O[jp] * scale + shift;
+    }
     int16_t *base = &s.res[(t < 16 ? t * 8 : 128 + (t - 16) * 8) + i];
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) {
-        const f32x2 o = O[jp] * scale + shift;
+        const f32x2 o = O[jp];
         const f32x2 q4 = o * splat2(0.25f);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -680,6 +742,13 @@ H263_DEV void recon_phase_idct_cols(const ReconArgs &, ReconWave &s, int lane, i
             base[(jp * 2 + h) * RES_STRIDE] = (int16_t)(int)clampf(v, -256.0f, 255.5f);
         }
     }
+}
+
+// whether a lane's block needs the class fix-ups of the column pass (the caller ORs this over the wave)
+H263_DEV bool recon_block_is_special(const RowIn &ri, int lane, uint64_t rows_any, uint64_t cols_any)
+{
+    const int slot = lane >> 3;
+    return ri.active && ((((uint32_t)(rows_any >> (8 * slot)) & 0xfeu) == 0) || (((uint32_t)(cols_any >> (8 * slot)) & 0xffu) == 0));
 }
 
 // ---- phase 5: interpolation + residual + clip + store ------------------------------------

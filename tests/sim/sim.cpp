@@ -58,19 +58,34 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
             WaveMasks km;
             km.valid = recon_valid_mask(a, p);
             km.act = km.inter = 0;
-            for (int l = 0; l < 64; l++) recon_phase_mark(a, *s, l, p, km);        // the lanes OR their bits into km
-            for (int l = 0; l < 64; l++) recon_phase_compact(a, *s, l, km);
+            static TaskInfo ti[64];
+            bool bad_index = false;
+            for (int l = 0; l < 64; l++) {                                  // the device kernel does these reductions with ballots
+                ti[l] = recon_phase_mark(a, *s, l, p, km.valid, recon_block_limit(a, p));
+                if (ti[l].active) km.act |= 1u << l;
+                if (ti[l].inter) km.inter |= 1u << (l - WAVE_TASKS);
+                bad_index = bad_index || ti[l].bad_index;
+            }
+            for (int l = 0; l < 64; l++) recon_report(a, l, km.inter && !a.has_ref, bad_index);
+            for (int l = 0; l < 64; l++) recon_phase_compact(*s, l, ti[l], km.act);
             for (int l = 0; l < 64; l++) recon_phase_fetch(a, *s, f[l], l, p, km);
             const int n_active = recon_n_active(km);
             for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
                 static RowIn ri[64];
                 uint32_t wm = 0, rm = 0;
+                uint64_t rows_any = 0, cols_any = 0;
+                bool any_special = false;
                 for (int l = 0; l < 64; l++) {
                     recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l], km);
-                    wm |= rowin_word_mask(ri[l]);          // the device kernel does these two reductions with ballots
+                    wm |= rowin_word_mask(ri[l]);
                 }
-                for (int l = 0; l < 64; l++) rm |= recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm)) ? 1u << (l & 7) : 0u;
-                for (int l = 0; l < 64; l++) recon_phase_idct_cols(a, *s, l, round, rows_from_mask(rm), km);
+                for (int l = 0; l < 64; l++) {
+                    const RowClass rc = recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm));
+                    if (rc.any) { rows_any |= 1ull << l; rm |= 1u << (l & 7); }
+                    if (rc.beyond_first) cols_any |= 1ull << l;
+                }
+                for (int l = 0; l < 64; l++) any_special = any_special || recon_block_is_special(ri[l], l, rows_any, cols_any);
+                for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special);
             }
             for (int l = 0; l < 64; l++) recon_phase_output(a, *s, f[l], l, p, km);
         }

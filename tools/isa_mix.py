@@ -105,7 +105,7 @@ def main():
     table = collections.OrderedDict()
     opcount = collections.Counter()
     for ph, ops in blocks:
-        border = any(o.startswith("v_lshrrev_b64") for o in ops)
+        border = sum(o.startswith("v_lshrrev_b64") for o in ops) >= 4
         row = table.setdefault(ph, {"main": collections.Counter(), "border": collections.Counter()})
         for o in ops:
             row["border" if border else "main"][classify(o)] += 1

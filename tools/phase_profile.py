@@ -17,7 +17,7 @@ L.h263mi_debug_read_phases.argtypes = [C.c_void_p, C.c_int]
 torch.cuda.set_device(0)
 stream = torch.cuda.current_stream().cuda_stream
 n = 64
-wl = bench.Workload(n, 9, 0, 0, stream)
+wl = bench.Workload(h263mi, n, 9, 0, 0, stream)
 batch = h263mi.Batch(n, bench.W, bench.H, 0, stream)
 buf = (C.c_ulonglong * 8)()
 names = ["records -> LDS", "mark + compact", "issue loads", "IDCT rounds", "wait reference rows", "output"]

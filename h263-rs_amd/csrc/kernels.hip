@@ -110,9 +110,10 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
             // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
             const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
                                 (__ballot(ri.w[3] != 0) ? 8u : 0u);
-            wave_fence();                           // the column pass of the previous round has read tbuf
-            const RowClass rc = recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm));
+            const RowClass rc = recon_row_class(ri, ln);
             const uint64_t rows_any = __ballot(rc.any), cols_any = __ballot(rc.beyond_first);      // bit slot*8 + row
+            wave_fence();                           // the column pass of the previous round has read tbuf
+            recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm), cols_any);
             uint32_t rows_mask = (uint32_t)rows_any | (uint32_t)(rows_any >> 32);
             rows_mask |= rows_mask >> 16;
             rows_mask |= rows_mask >> 8;

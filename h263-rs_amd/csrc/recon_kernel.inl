@@ -56,8 +56,8 @@ constexpr int RECON_HALVES = H263MI_RECON_HALVES;    // sub-tiles a wave process
 constexpr int TILE_MBX = 8, TILE_MBY = 2;      // macroblocks per workgroup
 constexpr int WAVE_TASKS = 24;                 // 16 luma + 8 chroma blocks per wave
 constexpr int ROUND_BLOCKS = 8;                // blocks per IDCT round (8 lanes each)
-constexpr int TBUF_ROW = 9;                    // floats per row of a block slot: T[r][0..7] and C[r][0]
-constexpr int TBUF_STRIDE = 8 * TBUF_ROW;      // 72 floats per slot: column reads are bank-conflict free
+constexpr int TBUF_ROW = 8;                    // floats per row of a block slot: T[r][0..7], written as two 16-byte stores
+constexpr int TBUF_STRIDE = 8 * TBUF_ROW + 8;  // 72 floats per slot: 8 pad floats make the column reads bank-conflict free
 constexpr int RES_STRIDE = 192;                // residual strip row: 128 luma + 64 chroma columns
 
 struct ReconWave {
@@ -65,7 +65,7 @@ struct ReconWave {
                                                // [1..4] the four vectors (x | y << 16), [5] intradc 0..3, [6] intradc 4..5, [7] coeff_index
     uint32_t mvc[TILE_MBX];                    // chroma vector per macroblock, x | y << 16 (gather.rs:182)
     uint32_t desc[WAVE_TASKS][2];              // descriptors of the active tasks, compacted (see TaskInfo)
-    float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results; column 8 of each row keeps C[r][0] for the Vert class
+    float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results T[r][i] of the round's 8 blocks
     int16_t  res[8 * RES_STRIDE];              // residual strip: 8 rows x (128 luma | 64 chroma) columns
 };
 static_assert(sizeof(MbRecord) == 32 && offsetof(MbRecord, mv) == 4 && offsetof(MbRecord, intradc) == 20 &&
@@ -262,6 +262,17 @@ typedef float f32x2 __attribute__((vector_size(8)));
 H263_CONST_TABLE float kBasis[8][8] = {H263MI_BASIS_ROWS};    // idct.rs:39-48
 
 H263_DEV f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
+// four consecutive floats (16-byte aligned) in one store
+H263_DEV void float4_store(float *dst, f32x2 a, f32x2 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v = {a[0], a[1], b[0], b[1]};
+    *reinterpret_cast<f32x4 *>(dst) = v;
+#else
+    dst[0] = a[0]; dst[1] = a[1]; dst[2] = b[0]; dst[3] = b[1];
+#endif
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) float (*BasisPtr)[8];     // constant address space: scalar loads
 #else
@@ -286,10 +297,14 @@ H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], 
 // Only the terms f < n are accumulated: the caller guarantees in[f] == 0 for f >= n, and adding a
 // zero product changes nothing but (again) the sign of a zero.  n is uniform over the wave, so the
 // early exits are scalar branches.
-H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n)
+H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n, bool first_term_raw = false)
 {
+    // first_term_raw: the row pass of a Vert / Dc block hands in[0] on unscaled (see recon_phase_idct_rows); row 0
+    // of the basis is one constant
+    // (idct.rs:40: BASIS_TABLE[0][i] = 0.70710677 for every i)
+    const f32x2 first = splat2(in[0]) * splat2(first_term_raw ? 1.0f : B[0][0]);
 #pragma unroll
-    for (int ip = 0; ip < 4; ip++) out[ip] = splat2(in[0]) * basis_pair(B, 0, ip);
+    for (int ip = 0; ip < 4; ip++) out[ip] = first;
 #pragma unroll
     for (int f = 1; f < 8; f++) {
         if (f >= n) break;
@@ -652,21 +667,37 @@ H263_DEV uint32_t rowin_word_mask(const RowIn &ri)
 
 // What a lane's coefficient row contributes to the classification of its block (rle.rs:138-149): a non-zero value
 // with y > 0 breaks "horiz", one with x > 0 breaks "vert".  A LEVEL is non-zero exactly when its dequantised value
-// is (|v| >= 3q - 1), so this is decided on the raw words.
+// is (|v| >= 3q - 1), so this is decided on the raw words -- before the row pass, which needs to know the class.
 struct RowClass {
     bool any;                  // the row holds a non-zero coefficient
     bool beyond_first;         // ... in a column x > 0
 };
 
-H263_DEV RowClass recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols)
+H263_DEV RowClass recon_row_class(const RowIn &ri, int lane)
 {
     RowClass rc = {false, false};
     if (!ri.active) return rc;
+    const bool use_dc = desc_intra(ri.d1) && (lane & 7) == 0;   // intra block: the DC comes from INTRADC (rle.rs:117-121)
+    rc.beyond_first = ((ri.w[0] >> 16) | ri.w[1] | ri.w[2] | ri.w[3]) != 0;
+    rc.any = rc.beyond_first || (use_dc ? desc_level(ri.d1) != 0 : (ri.w[0] & 0xffffu) != 0);
+    return rc;
+}
+
+// cols_any: bit slot*8 + r set when coefficient row r of the slot's block holds a non-zero value in a column x > 0
+// (the ballot of RowClass::beyond_first on the device).  A block none of whose rows does is Vert, Dc or Zero
+// (rle.rs:151-171): the reference does not run its first column through the row pass at all -- it transforms that
+// column directly (idct.rs:152-169) or uses the DC as it stands (idct.rs:119).  Here such a block runs the row
+// pass with 1.0 in the place of B[0][i]: T[r][i] = C[r][0] exactly, for every i, so that the column pass finds the
+// untouched first column in whichever column of T it reads.
+H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols, uint64_t cols_any)
+{
+    if (!ri.active) return;
     const int slot = lane >> 3, r = lane & 7;
     const uint32_t quant = desc_quant(ri.d1);
     // 2q and q - (q even) = (q - 1) | 1 in both halves of a dword
     const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = ((quant - 1u) | 1u) * 0x00010001u;
-    const bool use_dc = desc_intra(ri.d1) && r == 0;            // intra block: the DC comes from INTRADC (rle.rs:117-121)
+    const bool use_dc = desc_intra(ri.d1) && r == 0;
+    const bool first_column_only = ((uint32_t)(cols_any >> (8 * slot)) & 0xffu) == 0;
 
     float C[8];
 #pragma unroll
@@ -679,17 +710,12 @@ H263_DEV RowClass recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane,
         }
     }
     if (use_dc) C[0] = (float)(int)desc_level(ri.d1);
-    rc.beyond_first = ((ri.w[0] >> 16) | ri.w[1] | ri.w[2] | ri.w[3]) != 0;
-    rc.any = rc.beyond_first || (use_dc ? desc_level(ri.d1) != 0 : (ri.w[0] & 0xffffu) != 0);
 
     // idct_1d over the coefficient row (idct.rs:52-65)
     f32x2 T[4];
-    idct_1d_pairs(basis_table(), C, T, n_cols);
-    float *dst = &s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW];
-#pragma unroll
-    for (int i = 0; i < 8; i++) dst[i] = T[i >> 1][i & 1];
-    dst[8] = C[0];
-    return rc;
+    idct_1d_pairs(basis_table(), C, T, n_cols, first_column_only);
+    float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW], T[0], T[1]);
+    float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW + 4], T[2], T[3]);
 }
 
 // ---- phase 4b: column pass, rounding, residual strip -------------------------------------
@@ -705,12 +731,12 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
     const uint32_t slot_rows = (uint32_t)(rows_any >> (8 * slot)) & 0xfeu, slot_cols = (uint32_t)(cols_any >> (8 * slot)) & 0xffu;
     const bool is_horiz = slot_rows == 0, is_vert = slot_cols == 0;
 
-    // Vert (rle.rs:162-171, idct.rs:152-169) transforms the first column directly (kept in column 8
-    // of the slot); every other class reads column i of the row-pass result (the transposition of
-    // idct.rs:171-177).
+    // Every class reads column i of the row-pass result (the transposition of idct.rs:171-177); for the Vert class
+    // (rle.rs:162-171, idct.rs:152-169) and the Dc class that is the block's first coefficient column itself (see
+    // recon_phase_idct_rows).
     const bool vert = is_vert && !is_horiz;
     const bool dc_class = is_horiz && is_vert;                     // Dc or Zero, rle.rs:151-160
-    const float *src = &s.tbuf[slot * TBUF_STRIDE + (vert ? 8 : i)];
+    const float *src = &s.tbuf[slot * TBUF_STRIDE + i];
     float col[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) col[r] = r < n_rows ? src[r * TBUF_ROW] : 0.0f;       // uniform: rows >= n_rows are zero
@@ -722,7 +748,7 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
         // class fix-ups as one multiply and one add (both exact where they must not change the value):
         //   Vert: x * B[0][0] (idct.rs:160)          others: x * 1.0
         //   Dc  : x * 0 + dc * 0.5 (idct.rs:119: exactly 0.5, not B00*B00; dc = 0 gives the Zero class)
-        const float c00 = s.tbuf[slot * TBUF_STRIDE + 8];
+        const float c00 = col[0];
         const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? B[0][0] : 1.0f));
         const f32x2 shift = splat2(dc_class ? c00 * 0.5f : 0.0f);
 #pragma unroll

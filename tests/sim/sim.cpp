@@ -80,10 +80,11 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
                     wm |= rowin_word_mask(ri[l]);
                 }
                 for (int l = 0; l < 64; l++) {
-                    const RowClass rc = recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm));
+                    const RowClass rc = recon_row_class(ri[l], l);
                     if (rc.any) { rows_any |= 1ull << l; rm |= 1u << (l & 7); }
                     if (rc.beyond_first) cols_any |= 1ull << l;
                 }
+                for (int l = 0; l < 64; l++) recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm), cols_any);
                 for (int l = 0; l < 64; l++) any_special = any_special || recon_block_is_special(ri[l], l, rows_any, cols_any);
                 for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special);
             }

@@ -303,6 +303,20 @@ H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n, 
     // of the basis is one constant
     // (idct.rs:40: BASIS_TABLE[0][i] = 0.70710677 for every i)
     const f32x2 first = splat2(in[0]) * splat2(first_term_raw ? 1.0f : B[0][0]);
+#if defined(H263MI_MUTATE_PAIRWISE)
+    // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the eight rounded products summed as a balanced
+    // tree instead of in the order of the frequency index.  The parity suite must notice.
+#pragma unroll
+    for (int ip = 0; ip < 4; ip++) {
+        f32x2 pr[8];
+        pr[0] = first;
+#pragma unroll
+        for (int f = 1; f < 8; f++) pr[f] = splat2(in[f]) * basis_pair(B, f, ip);
+        out[ip] = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+    }
+    (void)n;
+    return;
+#endif
 #pragma unroll
     for (int ip = 0; ip < 4; ip++) out[ip] = first;
 #pragma unroll

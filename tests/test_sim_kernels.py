@@ -218,3 +218,22 @@ def test_expand_events_rebuilds_the_dense_blocks():
     evp = ev if ev.size else np.zeros(1, np.uint32)
     L.sim_expand(first.ctypes.data, evp.ctypes.data, out.ctypes.data, 37)
     assert (out == dense).all()
+
+
+def test_kernel_phases_on_the_mutation_sensitive_blocks():
+    """the committed blocks on which a fused or re-associated IDCT changes a pixel (tests/golden/
+    idct_sensitive_blocks.json) through the kernel phase functions on the CPU: same pixels as the reference arithmetic"""
+    import mutation_probe
+    blocks = mutation_probe.fixture()
+    w, h, intra, inter, coeffs = mutation_probe.records(blocks)
+    st, flat = simlib.recon(w, h, intra, np.zeros((0, 64), np.int16))
+    assert st == 0 and all((p == 128).all() for p in flat)
+    st, got = simlib.recon(w, h, inter, coeffs, ref=flat)
+    assert st == 0
+    want = np.full((h, w), 128, np.int32)
+    for k, b in enumerate(blocks):
+        px, py = (k % mutation_probe.MB_COLS) * 16, (k // mutation_probe.MB_COLS) * 16
+        want[py:py + 8, px:px + 8] += np.array(b["residual"], np.int32)
+    assert (got[0].reshape(h, w) == np.clip(want, 0, 255)).all()
+    rc, oracle_planes = orc.decode_picture(w, h, inter, coeffs, flat)
+    assert rc == 0 and (oracle_planes[0] == got[0]).all()

@@ -105,6 +105,10 @@ struct h263mi_batch {
         hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
     } host_stg[2];
     unsigned host_slot = 0;
+    // h263mi_batch_decode_next_pictures: what each stream remembers of its last picture header (state.rs:143-167)
+    // and the parse results of the current call (kept between calls so that their buffers are reused)
+    std::vector<bits::ParserContext> parser_ctx;
+    std::vector<bits::ParsedPicture> parsed;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -135,6 +139,7 @@ struct h263mi_batch {
         cur = good_cur = -1;
         has_ref = good_has_ref = false;
         unsynced_submits = 0;
+        parser_ctx.clear();
     }
 
     void release_frames()
@@ -652,6 +657,70 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type, const
 {
     if (!block_first_event) return H263MI_ERR_INVALID_ARGUMENT;
     return batch_submit_host(b, picture_type, mbs, n_mbs, nullptr, n_coeff_blocks, block_first_event, events, n_events);
+}
+
+int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
+                                      const size_t *len, size_t *consumed, uint32_t n_threads)
+{
+    if (!b || !data || !len) return H263MI_ERR_INVALID_ARGUMENT;
+    const uint32_t n = b->n;
+    for (uint32_t i = 0; i < n; i++)
+        if (!data[i] && len[i]) return H263MI_ERR_INVALID_ARGUMENT;
+    if (b->parser_ctx.size() != n) b->parser_ctx.assign(n, bits::ParserContext());
+    if (b->parsed.size() != n) b->parsed.resize(n);
+    // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
+    std::vector<int> rcs(n, H263MI_OK);
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            bits::ParsedPicture &pic = b->parsed[i];
+            pic.want_dense = false;                              // the coefficients travel as events
+            rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
+        }
+    };
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : hw, n, 256u}));
+    if (n_thr == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < n_thr; t++) pool.emplace_back(work);
+        for (std::thread &t : pool) t.join();
+    }
+    // Any stream's error fails the call before anything is queued: the batch -- frames, reference bookkeeping and
+    // what it remembers of the picture headers -- is unchanged (state.rs:142).
+    uint8_t picture_type = H263MI_PICTURE_I;
+    bool all_disposable = true;
+    for (uint32_t i = 0; i < n; i++) {
+        if (rcs[i] != H263MI_OK) return rcs[i];
+        const h263mi_picture_desc &d = b->parsed[i].desc;
+        if (d.width != b->L.width || d.height != b->L.height) return H263MI_ERR_PICTURE_FORMAT_INVALID;
+        if (d.picture_type != H263MI_PICTURE_I) picture_type = H263MI_PICTURE_P;
+        if (d.picture_type != H263MI_PICTURE_DISPOSABLE_P) all_disposable = false;
+    }
+    // Streams advance in lock step but need not agree on the picture type: the records say which macroblocks
+    // predict.  For the reference store (state.rs:464-483) the batch picture is an I picture when every stream's
+    // is, disposable when every stream's is, else a P picture.
+    if (all_disposable) picture_type = H263MI_PICTURE_DISPOSABLE_P;
+    std::vector<const h263mi_mb_record *> mbs(n);
+    std::vector<const uint32_t *> first(n), events(n);
+    std::vector<uint32_t> n_mbs(n), n_blocks(n), n_events(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const bits::ParsedPicture &pic = b->parsed[i];
+        mbs[i] = pic.mbs.data();
+        n_mbs[i] = (uint32_t)pic.mbs.size();
+        first[i] = pic.block_first_event.data();
+        events[i] = pic.events.data();
+        n_blocks[i] = (uint32_t)pic.n_coded_blocks;
+        n_events[i] = (uint32_t)pic.events.size();
+    }
+    RC_TRY(batch_submit_host(b, picture_type, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
+                             n_events.data()));
+    for (uint32_t i = 0; i < n; i++) {
+        b->parser_ctx[i] = b->parsed[i].next;
+        if (consumed) consumed[i] = b->parsed[i].bits_consumed / 8;          // reader.commit() drains whole bytes
+    }
+    return H263MI_OK;
 }
 
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)

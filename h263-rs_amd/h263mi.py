@@ -63,7 +63,7 @@ EXPORTS = [
     "h263mi_get_last_picture", "h263mi_get_reference_picture", "h263mi_copy_yuv", "h263mi_render_rgba",
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
-    "h263mi_batch_decode",
+    "h263mi_batch_decode", "h263mi_batch_decode_next_pictures",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
     "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_timing_reserve", "h263mi_probe_bandwidth",
     "h263mi_batch_submit_host", "h263mi_submit_picture_events", "h263mi_batch_submit_host_events",
@@ -148,6 +148,7 @@ def lib():
         L.h263mi_batch_mbs_per_picture.restype = u32
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
         L.h263mi_batch_decode.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp]
+        L.h263mi_batch_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32]
         L.h263mi_batch_submit_host.argtypes = [vp, u8, vp, vp, vp, vp]
         L.h263mi_batch_submit_host_events.argtypes = [vp, u8, vp, vp, vp, vp, vp, vp]
         L.h263mi_batch_render_rgba.argtypes = [vp, u8, vp, vp]
@@ -402,6 +403,22 @@ class Batch:
         """submit + render_rgba in one call (h263mi_batch_decode)"""
         _check(lib().h263mi_batch_decode(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength,
                                          d_rgba, d_deblocked), "batch_decode")
+
+    def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None):
+        """one coded picture per stream (bytes-like objects) through the host parser threads and the GPU; returns the
+        bytes consumed per stream.  `prepared` (from prepare_pictures) skips the per-call ctypes marshalling."""
+        pd, ln, keep = prepared if prepared is not None else self.prepare_pictures(data_list)
+        used = (C.c_size_t * self.n)()
+        _check(lib().h263mi_batch_decode_next_pictures(self._h, decoder_options, pd, ln, used, n_threads),
+               "batch_decode_next_pictures")
+        return list(used)
+
+    def prepare_pictures(self, data_list):
+        assert len(data_list) == self.n
+        keep = [np.frombuffer(bytes(d), dtype=np.uint8) for d in data_list]
+        pd = (C.c_void_p * self.n)(*[k.ctypes.data if k.size else None for k in keep])
+        ln = (C.c_size_t * self.n)(*[k.size for k in keep])
+        return pd, ln, keep
 
     def submit_host(self, picture_type, mbs_list, coeffs_list):
         """one picture per stream from host records: lists of MB_RECORD_DTYPE arrays and (n, 64) int16 arrays"""

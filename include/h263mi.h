@@ -308,6 +308,18 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
                                     const h263mi_mb_record *const *mbs, const uint32_t *n_mbs,
                                     const uint32_t *const *block_first_event, const uint32_t *n_coeff_blocks,
                                     const uint32_t *const *events, const uint32_t *n_events);
+/*
+ * N x H263State::decode_next_picture(reader) (state.rs:138-141) in one call: data[s] / len[s] hold one coded picture
+ * of stream s (what Ruffle hands one reader per FLV video tag).  The serial parse of each stream (state.rs:143-427)
+ * runs on `n_threads` host threads (0 = one per hardware thread), one stream per task; the records of all streams
+ * then cross to the device as events (h263mi_batch_submit_host_events) and one k_recon launch decodes them.
+ * consumed[s] (may be NULL) receives the bytes used.  decoder_options as for h263mi_state_new.  If any stream fails
+ * to parse, the error of the first such stream is returned and NOTHING changes for any stream.  Every picture must
+ * have the batch's width and height.  The host parser is the bit-at-a-time reader of the reference (reader.rs:94-134,
+ * 272-290) redesigned around a 64-bit window and table lookups (h263-rs_amd/host/bitstream.cpp).
+ */
+int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
+                                      const size_t *len, size_t *consumed, uint32_t n_threads);
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_sync(h263mi_batch *b);
 int h263mi_batch_reset(h263mi_batch *b);

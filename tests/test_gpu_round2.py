@@ -225,3 +225,55 @@ def test_probe_bandwidth_reports_a_plausible_ceiling():
     write = h263mi.probe_bandwidth(h263mi.PROBE_WRITE, 256 << 20, 5)
     for v in (copy, read, write):
         assert 500.0 < v < 20000.0, (copy, read, write)
+
+
+# ---------------------------------------------------------------------------------------------
+# N x decode_next_picture(bytes) in one call: parser threads -> events -> one launch
+# ---------------------------------------------------------------------------------------------
+def test_batch_decode_next_pictures_from_bitstreams():
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    w, h, n = 176, 144, 5
+    b = h263mi.Batch(n, w, h)
+    refs = [None] * n
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+    cw = (w + 1) // 2
+    for f in range(4):
+        datas, recs = [], []
+        for s in range(n):
+            q = 4 + 3 * s
+            if f == 0:
+                mbs, co = recgen.intra_picture(w, h, seed=50 + s, max_level=60)
+                mbs = make_codable(mbs, q, s, 0)
+            else:
+                mbs, co = recgen.inter_picture(w, h, seed=100 * f + s, mv_range=32, p_4v=0.3, p_intra=0.1, p_coded=0.4,
+                                               quant=q, max_level=60)
+                mbs = make_codable(mbs, q, s + f, 1)
+            datas.append(enc.encode_picture(w, h, 0 if f == 0 else 1, q, mbs, co, temporal_reference=f))
+            recs.append((mbs, co))
+        used = b.decode_next_pictures(datas, n_threads=3)
+        b.render_rgba(5, d_rgba.ptr)
+        b.sync()
+        for s in range(n):
+            assert 0 < used[s] <= len(datas[s])
+            rc, refs[s] = orc.decode_picture(w, h, recs[s][0], recs[s][1], refs[s] if f else None)
+            assert rc == 0
+            assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
+            filt = tuple(orc.deblock(p, pw, 5) for p, pw in zip(refs[s], (w, cw, cw)))
+            assert (d_rgba.download(w * h * 4, s * w * h * 4) == orc.yuv420_to_rgba(*filt, w)).all()
+    # one broken stream fails the call and changes nothing for any stream
+    before = [b.copy_yuv(s) for s in range(n)]
+    broken = list(datas)
+    broken[3] = broken[3][:5]
+    with pytest.raises(h263mi.H263Error):
+        b.decode_next_pictures(broken)
+    b.sync()
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), before[s], "after the failed call")
+    # a picture of another size is refused
+    mbs, co = recgen.intra_picture(128, 96, seed=1, max_level=60)
+    other = enc.encode_picture(128, 96, 0, 7, make_codable(mbs, 7, 1, 0), co)
+    with pytest.raises(h263mi.H263Error) as e:
+        b.decode_next_pictures([other] * n)
+    assert e.value.code == h263mi.ERR_PICTURE_FORMAT_INVALID
+    b.close()

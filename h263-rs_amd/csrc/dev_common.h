@@ -140,6 +140,105 @@ struct PostArgs {
 // ---------------------------------------------------------------------------
 H263_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---------------------------------------------------------------------------
+// packed 16-bit integer arithmetic: both halves of a dword at once (one v_pk_* instruction each on the device,
+// plain C on the two halves in the CPU logic checker).  Wrapping, like i16 arithmetic in a release build of the
+// reference.  Shift counts are compile-time constants.
+// ---------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define H263_PK_ASM2(insn, x, y) uint32_t r_; asm(insn " %0, %1, %2" : "=v"(r_) : "v"(x), "v"(y)); return r_
+#define H263_PK_SHIFT(insn, x, n) uint32_t r_; asm(insn " %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r_) : "n"(n), "v"(x)); return r_
+#endif
+#define H263_PK_HALVES(expr)                                                                     \
+    uint32_t out_ = 0;                                                                           \
+    for (int h_ = 0; h_ < 2; h_++) {                                                             \
+        const int a = (int16_t)(x >> (16 * h_)), b = (int16_t)(y >> (16 * h_));                  \
+        out_ |= ((uint32_t)(expr) & 0xffffu) << (16 * h_);                                       \
+    }                                                                                            \
+    return out_
+H263_DEV uint32_t pk_add_u16(uint32_t x, uint32_t y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_ASM2("v_pk_add_u16", x, y);
+#else
+    H263_PK_HALVES(a + b);
+#endif
+}
+H263_DEV uint32_t pk_sub_u16(uint32_t x, uint32_t y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_ASM2("v_pk_sub_u16", x, y);
+#else
+    H263_PK_HALVES(a - b);
+#endif
+}
+H263_DEV uint32_t pk_max_i16(uint32_t x, uint32_t y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_ASM2("v_pk_max_i16", x, y);
+#else
+    H263_PK_HALVES(a > b ? a : b);
+#endif
+}
+H263_DEV uint32_t pk_min_i16(uint32_t x, uint32_t y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_ASM2("v_pk_min_i16", x, y);
+#else
+    H263_PK_HALVES(a < b ? a : b);
+#endif
+}
+H263_DEV uint32_t pk_mad_i16(uint32_t x, uint32_t y, uint32_t z)        // x * y + z per half
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+#else
+    uint32_t out = 0;
+    for (int h = 0; h < 2; h++)
+        out |= ((uint32_t)((int16_t)(x >> (16 * h)) * (int16_t)(y >> (16 * h)) + (int16_t)(z >> (16 * h))) & 0xffffu) << (16 * h);
+    return out;
+#endif
+}
+H263_DEV uint32_t pk_ashr_i16(uint32_t x, uint32_t n)           // arithmetic shift right of both halves by the constant n
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_SHIFT("v_pk_ashrrev_i16", x, n);
+#else
+    const uint32_t lo = (uint32_t)((int16_t)(x & 0xffffu) >> n) & 0xffffu, hi = (uint32_t)((int16_t)(x >> 16) >> n) & 0xffffu;
+    return lo | (hi << 16);
+#endif
+}
+H263_DEV uint32_t pk_lshr_u16(uint32_t x, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_SHIFT("v_pk_lshrrev_b16", x, n);
+#else
+    return ((x & 0xffffu) >> n) | (((x >> 16) >> n) << 16);
+#endif
+}
+H263_DEV uint32_t pk_lshl_u16(uint32_t x, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    H263_PK_SHIFT("v_pk_lshlrev_b16", x, n);
+#else
+    return ((x << n) & 0xffffu) | ((((x >> 16) << n) & 0xffffu) << 16);
+#endif
+}
+// both halves saturated to 0..255; the two bytes arrive in bits 15:0 (bits 31:16 are not to be relied upon)
+H263_DEV uint32_t sat_pk_u8_i16(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    const int a = (int16_t)(x & 0xffffu), b = (int16_t)(x >> 16);
+    return (uint32_t)(a < 0 ? 0 : (a > 255 ? 255 : a)) | ((uint32_t)(b < 0 ? 0 : (b > 255 ? 255 : b)) << 8);
+#endif
+}
+
 // types.rs:955-961 IntraDc::into_level
 H263_HD int intradc_level(uint32_t code) { return code == 0xFFu ? 1024 : (int)(code << 3); }
 

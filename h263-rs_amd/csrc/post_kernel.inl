@@ -101,6 +101,71 @@ H263_HD void deblock_quartet(int &A, int &B, int &C, int &D, int strength, bool 
     deblock_quartet_tm(A, B, C, D, strength, floor_sem ? 0 : -1);
 }
 
+// TWO quartets at once, one in each 16-bit half of a dword (v_pk_* instructions on the device): the same formula as
+// deblock_quartet_tm -- every intermediate fits 12 bits.  k carries the per-position constants in both halves.
+// In: byte values 0..255 per half.  Out: A and D wrapped results in the LOW BYTE of each half (the reference's
+// `as u8`, deblock.rs:38,41); B and C unsaturated (-255..510): the caller packs them with a saturating pack, which
+// is the clamp of deblock.rs:39-40.
+struct QuartetConsts {
+    uint32_t s2;               // 2 * strength
+    uint32_t c7, c3;           // 7 & tm, 3 & tm: the bias that turns the shifts into truncating divisions
+    uint32_t c1;               // 1 & ~tm: |d1 / 2| rounds away from zero for a negative d1 under floor division
+};
+H263_HD QuartetConsts quartet_consts(int strength, int tm)
+{
+    QuartetConsts k;
+    k.s2 = (uint32_t)(2 * strength) * 0x00010001u;
+    k.c7 = 0x00070007u & (uint32_t)tm;
+    k.c3 = 0x00030003u & (uint32_t)tm;
+    k.c1 = 0x00010001u & ~(uint32_t)tm;
+    return k;
+}
+H263_DEV void deblock_quartet_pk(uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D, const QuartetConsts &k)
+{
+    const uint32_t adm = pk_sub_u16(A, D);
+    const uint32_t x = pk_mad_i16(pk_sub_u16(C, B), 0x00040004u, adm);
+    const uint32_t d = pk_ashr_i16(pk_add_u16(x, pk_ashr_i16(x, 15) & k.c7), 3);
+    const uint32_t sd = pk_ashr_i16(d, 15);                                   // 0 or -1 per half
+    const uint32_t ad = pk_max_i16(d, pk_sub_u16(0u, d));                     // |d|
+    const uint32_t mag = pk_max_i16(pk_min_i16(ad, pk_sub_u16(k.s2, ad)), 0u);   // up_down_ramp = median(0, |d|, 2S - |d|)
+    const uint32_t d1 = pk_sub_u16(mag ^ sd, sd);
+    const uint32_t lim = pk_lshr_u16(pk_add_u16(mag, sd & k.c1), 1);          // |d1 / 2| in the division of this position
+    const uint32_t q = pk_ashr_i16(pk_add_u16(adm, pk_ashr_i16(adm, 15) & k.c3), 2);
+    const uint32_t d2 = pk_max_i16(pk_min_i16(q, lim), pk_sub_u16(0u, lim));   // clipd1
+    A = pk_sub_u16(A, d2);
+    B = pk_add_u16(B, d1);
+    C = pk_sub_u16(C, d1);
+    D = pk_add_u16(D, d2);
+}
+
+// byte k0 of x into bits 7:0, byte k1 into bits 23:16, zeros elsewhere: two bytes as an i16 pair
+H263_DEV uint32_t bytes_to_pair(uint32_t x, int k0, int k1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, x, 0x0c000c00u | (uint32_t)k0 | ((uint32_t)k1 << 16));
+#else
+    return ((x >> (8 * k0)) & 0xffu) | (((x >> (8 * k1)) & 0xffu) << 16);
+#endif
+}
+// the same with the two bytes taken from two dwords: byte k of lo_src -> bits 7:0, byte k of hi_src -> bits 23:16
+H263_DEV uint32_t bytes_to_pair2(uint32_t lo_src, uint32_t hi_src, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x0c000c00u | (uint32_t)k | ((uint32_t)(4 + k) << 16));
+#else
+    return ((lo_src >> (8 * k)) & 0xffu) | (((hi_src >> (8 * k)) & 0xffu) << 16);
+#endif
+}
+// low bytes of the two halves of an i16 pair -> bits 7:0 and 15:8
+H263_DEV uint32_t pair_low_bytes(uint32_t p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, p, 0x0c0c0200u);
+#else
+    return (p & 0xffu) | (((p >> 16) & 0xffu) << 8);
+#endif
+}
+
 // tm for position `pos` against the end of the reference's SIMD region: 0 (floor) for pos < simd_end, else -1
 H263_HD int trunc_mask(int pos, int simd_end) { return (simd_end - 1 - pos) >> 31; }
 
@@ -183,22 +248,28 @@ H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch
     }
 }
 
-// filter 2 neighbouring columns of the horizontal edge whose A row is `row_a`
+// filter 2 neighbouring columns of the horizontal edge whose A row is `row_a`: one packed quartet pair.
+// Columns outside the picture (the strip's 4-pixel offset, the right picture edge) keep their bytes.
 H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, int gx0, int floor_cols, int w)
 {
     uint32_t r[4];
-    int v[2][4];
 #pragma unroll
     for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col);
+    // the two columns are 2k, 2k+1 and floor_cols is a multiple of 8: both lie on the same side of it
+    const QuartetConsts k = quartet_consts(strength, trunc_mask(gx0, floor_cols));
+    uint32_t A = bytes_to_pair(r[0], 0, 1), B = bytes_to_pair(r[1], 0, 1), C = bytes_to_pair(r[2], 0, 1), D = bytes_to_pair(r[3], 0, 1);
+    deblock_quartet_pk(A, B, C, D, k);
+    uint32_t o[4] = {pair_low_bytes(A), sat_pk_u8_i16(B), sat_pk_u8_i16(C), pair_low_bytes(D)};
+    const uint32_t keep = (gx0 >= 0 && gx0 < w ? 0u : 0x00ffu) | (gx0 + 1 >= 0 && gx0 + 1 < w ? 0u : 0xff00u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(keep != 0))                                // uniform: only tiles at the left / right picture edge
+#endif
+    {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[k][q] = (int)((r[q] >> (8 * k)) & 0xff);
-        const int gx = gx0 + k;
-        if (gx >= 0 && gx < w) deblock_quartet_tm(v[k][0], v[k][1], v[k][2], v[k][3], strength, trunc_mask(gx, floor_cols));
+        for (int q = 0; q < 4; q++) o[q] = (o[q] & ~keep) | (r[q] & keep);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col) = (uint16_t)pack2_u8(v[0][q], v[1][q]);
+    for (int q = 0; q < 4; q++) *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col) = (uint16_t)o[q];
 }
 
 // ---- phase 1: the horizontal block edge of the strip (deblock_horiz, deblock.rs:136-181) ------
@@ -222,38 +293,64 @@ H263_DEV void post_phase_hedges(const PostArgs &a, PostStrip &s, int lane, int s
 }
 
 // ---- phase 2: vertical block edges (deblock_vert, deblock.rs:185-299) ----------------------
+// A lane takes the same edge in two vertically adjacent rows 2q, 2q + 1 -- one packed quartet pair.  The strip origin
+// is 4 (mod 8) in y (2 mod 4 for chroma), so a row pair never straddles a multiple of 8: both rows divide alike.
 H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int sx, int sy)
 {
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
     const int strength = (int)a.strength;
-    // luma: 8 rows x 16 edges; the quartet sits in bytes 2..5 of an aligned 8-byte window
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int row = (lane >> 4) + 4 * it, j = lane & 15;
+    {
+        // luma: 4 row pairs x 16 edges; the quartet sits in bytes 2..5 of an aligned 8-byte window
+        const int row = (lane >> 4) * 2, j = lane & 15;
         const int gy = yl + row, gxa = xl + 8 * j + 2;         // picture column of the "A" sample
         const int w = (int)a.L.width, h = (int)a.L.height;
         // A..D = columns 8k-2 .. 8k+1 with k >= 1 and 8k+1 <= w-1 (chunks of row[2..], deblock.rs:281)
-        if (gy >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
-            uint64_t v = *reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]);
-            int A = (v >> 16) & 0xff, B = (v >> 24) & 0xff, C = (v >> 32) & 0xff, D = (v >> 40) & 0xff;
-            deblock_quartet_tm(A, B, C, D, strength, trunc_mask(gy, (h / 8) * 8));
-            const uint32_t lo = splice_lo16_hi16((uint32_t)v, pack2_u8(A, B));
-            const uint32_t hi = splice_put16_keep16(pack2_u8(C, D), (uint32_t)(v >> 32));
-            *reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]) = (uint64_t)lo | ((uint64_t)hi << 32);
+        if (gy + 1 >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
+            uint64_t *p0 = reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]);
+            uint64_t *p1 = reinterpret_cast<uint64_t *>(&s.y[(row + 1) * POST_TW + 8 * j]);
+            const uint64_t v0 = *p0, v1 = *p1;
+            const uint32_t l0 = (uint32_t)v0, h0 = (uint32_t)(v0 >> 32), l1 = (uint32_t)v1, h1 = (uint32_t)(v1 >> 32);
+            uint32_t A = bytes_to_pair2(l0, l1, 2), B = bytes_to_pair2(l0, l1, 3), C = bytes_to_pair2(h0, h1, 0), D = bytes_to_pair2(h0, h1, 1);
+            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
+            // ab = [A'0, B'0, A'1, B'1], cd = [C'0, D'0, C'1, D'1] as bytes
+            const uint32_t bs = sat_pk_u8_i16(B), cs = sat_pk_u8_i16(C);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t ab = __builtin_amdgcn_perm(bs, A, 0x05020400u), cd = __builtin_amdgcn_perm(D, cs, 0x06010400u);
+            const uint32_t nl0 = __builtin_amdgcn_perm(ab, l0, 0x05040100u), nl1 = __builtin_amdgcn_perm(ab, l1, 0x07060100u);
+            const uint32_t nh0 = __builtin_amdgcn_perm(cd, h0, 0x03020504u), nh1 = __builtin_amdgcn_perm(cd, h1, 0x03020706u);
+#else
+            const uint32_t a0 = A & 0xffu, a1 = (A >> 16) & 0xffu, b0 = bs & 0xffu, b1 = (bs >> 8) & 0xffu;
+            const uint32_t c0 = cs & 0xffu, c1 = (cs >> 8) & 0xffu, d0 = D & 0xffu, d1 = (D >> 16) & 0xffu;
+            const uint32_t nl0 = (l0 & 0xffffu) | (a0 << 16) | (b0 << 24), nl1 = (l1 & 0xffffu) | (a1 << 16) | (b1 << 24);
+            const uint32_t nh0 = (h0 & 0xffff0000u) | c0 | (d0 << 8), nh1 = (h1 & 0xffff0000u) | c1 | (d1 << 8);
+#endif
+            // rows outside the picture (above the first strip, below the last row) keep their bytes
+            if (gy >= 0) *p0 = (uint64_t)nl0 | ((uint64_t)nh0 << 32);
+            if (gy + 1 < h) *p1 = (uint64_t)nl1 | ((uint64_t)nh1 << 32);
         }
     }
     if (a.luma_only) return;
-    // chroma: 2 planes x 4 rows x 8 edges; the quartet is bytes 4..7 of an aligned 8-byte window
-    {
-        const int plane = lane >> 5, row = (lane >> 3) & 3, j = lane & 7;
+    // chroma: 2 planes x 2 row pairs x 8 edges on lanes 0..31; the quartet is bytes 4..7 of an aligned 8-byte window
+    if (lane < 32) {
+        const int plane = lane >> 4, row = ((lane >> 3) & 1) * 2, j = lane & 7;
         const int gy = yl / 2 + row, gxa = xl / 2 + 8 * j + 4;
         const int w = (int)a.L.cwidth, h = (int)a.L.cheight;
-        if (gy >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
-            uint32_t v = *reinterpret_cast<uint32_t *>(&s.c[plane][row * POST_CW + 8 * j + 4]);
-            int A = v & 0xff, B = (v >> 8) & 0xff, C = (v >> 16) & 0xff, D = (v >> 24) & 0xff;
-            deblock_quartet_tm(A, B, C, D, strength, trunc_mask(gy, (h / 8) * 8));
-            v = splice_lo16_hi16(pack2_u8(A, B), pack2_u8(C, D));
-            *reinterpret_cast<uint32_t *>(&s.c[plane][row * POST_CW + 8 * j + 4]) = v;
+        if (gy + 1 >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
+            uint32_t *p0 = reinterpret_cast<uint32_t *>(&s.c[plane][row * POST_CW + 8 * j + 4]);
+            uint32_t *p1 = reinterpret_cast<uint32_t *>(&s.c[plane][(row + 1) * POST_CW + 8 * j + 4]);
+            const uint32_t v0 = *p0, v1 = *p1;
+            uint32_t A = bytes_to_pair2(v0, v1, 0), B = bytes_to_pair2(v0, v1, 1), C = bytes_to_pair2(v0, v1, 2), D = bytes_to_pair2(v0, v1, 3);
+            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
+            const uint32_t bs = sat_pk_u8_i16(B), cs = sat_pk_u8_i16(C);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t ab = __builtin_amdgcn_perm(bs, A, 0x05020400u), cd = __builtin_amdgcn_perm(D, cs, 0x06010400u);
+            const uint32_t n0 = __builtin_amdgcn_perm(cd, ab, 0x05040100u), n1 = __builtin_amdgcn_perm(cd, ab, 0x07060302u);
+#else
+            const uint32_t n0 = (A & 0xffu) | ((bs & 0xffu) << 8) | ((cs & 0xffu) << 16) | ((D & 0xffu) << 24);
+            const uint32_t n1 = ((A >> 16) & 0xffu) | (((bs >> 8) & 0xffu) << 8) | (((cs >> 8) & 0xffu) << 16) | (((D >> 16) & 0xffu) << 24);
+#endif
+            if (gy >= 0) *p0 = n0;
+            if (gy + 1 < h) *p1 = n1;
         }
     }
 }

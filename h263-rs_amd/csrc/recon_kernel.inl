@@ -189,39 +189,6 @@ H263_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 #endif
 }
 
-// packed 16-bit integer helpers (both halves of a dword at once; wrapping like the reference's i16 arithmetic)
-H263_DEV uint32_t pk_add_u16(uint32_t x, uint32_t y)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-#else
-    return ((x + y) & 0xffffu) | (((x >> 16) + (y >> 16)) << 16);
-#endif
-}
-H263_DEV uint32_t pk_ashr_i16(uint32_t x, uint32_t n)          // arithmetic shift right of both halves by the constant n
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_pk_ashrrev_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "n"(n), "v"(x));
-    return r;
-#else
-    const uint32_t lo = (uint32_t)((int16_t)(x & 0xffffu) >> n) & 0xffffu, hi = (uint32_t)((int16_t)(x >> 16) >> n) & 0xffffu;
-    return lo | (hi << 16);
-#endif
-}
-H263_DEV uint32_t pk_lshl_u16(uint32_t x, uint32_t n)          // shift left of both halves by the constant n
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "n"(n), "v"(x));
-    return r;
-#else
-    return ((x << n) & 0xffffu) | (((x >> 16) << n) << 16);
-#endif
-}
-
 // four prediction bytes + four i16 residuals (two dwords) -> four clipped bytes
 // (clipped_idct + mocomp_pixel).clamp(0, 255)  idct.rs:127-130, 191-194
 H263_DEV uint32_t add_clip_u8x4(uint32_t pred, uint32_t r01, uint32_t r23)
@@ -231,9 +198,7 @@ H263_DEV uint32_t add_clip_u8x4(uint32_t pred, uint32_t r01, uint32_t r23)
     const uint32_t p23 = __builtin_amdgcn_perm(0u, pred, 0x0c030c02u);       // (p2, p3)
     // v_sat_pk_u8_i16: both halves saturated to 0..255 and packed into bits 15:0 (what it leaves in bits 31:16 is
     // not relied upon: the permute below picks bytes 0 and 1 of each)
-    uint32_t b01, b23;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(pk_add_u16(p01, r01)));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(pk_add_u16(p23, r23)));
+    const uint32_t b01 = sat_pk_u8_i16(pk_add_u16(p01, r01)), b23 = sat_pk_u8_i16(pk_add_u16(p23, r23));
     return __builtin_amdgcn_perm(b23, b01, 0x05040100u);
 #else
     uint32_t out = 0;

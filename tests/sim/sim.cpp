@@ -184,6 +184,20 @@ int sim_quartet_sweep(void (*ref)(uint8_t *, uint8_t *, uint8_t *, uint8_t *, ui
                             if (!bad) { first[0] = a0; first[1] = b0; first[2] = c0; first[3] = d0; first[4] = strength; }
                             bad++;
                         }
+                        // the packed form (two quartets per dword): this quartet in the low halves, its mirror image
+                        // D,C,B,A in the high halves -- the mirror must come out as the mirrored result
+                        // (deblock.rs:352-439 checks the same symmetry)
+                        uint32_t pA = (uint32_t)a0 | ((uint32_t)d0 << 16), pB = (uint32_t)b0 | ((uint32_t)c0 << 16);
+                        uint32_t pC = (uint32_t)c0 | ((uint32_t)b0 << 16), pD = (uint32_t)d0 | ((uint32_t)a0 << 16);
+                        deblock_quartet_pk(pA, pB, pC, pD, quartet_consts(strength, floor_sem ? 0 : -1));
+                        const uint32_t sb = sat_pk_u8_i16(pB), sc = sat_pk_u8_i16(pC);
+                        uint8_t ma = (uint8_t)d0, mb = (uint8_t)c0, mc = (uint8_t)b0, md = (uint8_t)a0;
+                        ref(&ma, &mb, &mc, &md, (uint8_t)strength);
+                        if ((pA & 0xff) != ra || (sb & 0xff) != rb || (sc & 0xff) != rc || (pD & 0xff) != rd ||
+                            ((pA >> 16) & 0xff) != ma || ((sb >> 8) & 0xff) != mb || ((sc >> 8) & 0xff) != mc || ((pD >> 16) & 0xff) != md) {
+                            if (!bad) { first[0] = a0; first[1] = b0; first[2] = c0; first[3] = d0; first[4] = -strength; }
+                            bad++;
+                        }
                     }
     return bad;
 }

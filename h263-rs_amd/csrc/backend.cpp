@@ -79,6 +79,16 @@ struct h263mi_batch {
     hipStream_t post_stream = nullptr;
     hipEvent_t ev_recon_done = nullptr, ev_post_done[2] = {nullptr, nullptr};   // post events per frame set
     bool overlap_post = false;
+    // H263MI_CFG_PIPELINE_POST: h263mi_batch_decode defers the post-processing of a picture to the launch that
+    // reconstructs the NEXT one (k_frame: both read the same frame set, see kernels.hip); `pending` is that deferred
+    // half.  Flushed (as a plain k_post launch) by sync, render, submit, reset.
+    bool pipeline_post = false;
+    struct PendingPost {
+        bool valid = false;
+        uint8_t strength = 0;
+        uint8_t *rgba = nullptr, *planes = nullptr;
+        int set = -1;                          // frame set it reads
+    } pending;
     uint32_t n = 0;
     FrameLayout L{};
     uint8_t *frames[2] = {nullptr, nullptr};   // ping-pong frame sets, n * frame_bytes each
@@ -136,6 +146,7 @@ struct h263mi_batch {
 
     void forget_pictures()
     {
+        (void)flush_pending();                 // what was asked to be rendered still is
         cur = good_cur = -1;
         has_ref = good_has_ref = false;
         unsynced_submits = 0;
@@ -215,6 +226,7 @@ struct h263mi_batch {
         return H263MI_OK;
     }
 
+    // kernel ids of the timing: 0 k_recon, 1 k_post, 2 k_frame
     hipStream_t stream_of(int kernel_id) const { return (kernel_id == 1 && overlap_post) ? post_stream : stream; }
 
     int time_begin(int kernel_id)
@@ -239,9 +251,12 @@ struct h263mi_batch {
         return H263MI_OK;
     }
 
-    // state.rs:432-483 for every stream of the batch
-    int submit(uint8_t picture_type, const MbRecord *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base)
+    // state.rs:432-483 for every stream of the batch.  post: the deferred post-processing to run in the same launch
+    // (pipeline mode), or null.
+    int submit(uint8_t picture_type, const MbRecord *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
+               const PostArgs *post = nullptr)
     {
+        if (!post) RC_TRY(flush_pending());
         const int out = cur < 0 ? 0 : (cur ^ 1);
         ReconArgs a{};
         a.L = L;
@@ -261,9 +276,15 @@ struct h263mi_batch {
         a.tiles_y = recon_tiles_y(L);
         // the set being overwritten was last read by the post-processing of the picture before the last one
         if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out], 0));
-        RC_TRY(time_begin(0));
-        HIP_TRY(launch_recon(a, stream));
-        RC_TRY(time_end(0));
+        if (post) {
+            RC_TRY(time_begin(2));
+            HIP_TRY(launch_frame(a, *post, stream));
+            RC_TRY(time_end(2));
+        } else {
+            RC_TRY(time_begin(0));
+            HIP_TRY(launch_recon(a, stream));
+            RC_TRY(time_end(0));
+        }
         if (overlap_post) HIP_TRY(hipEventRecord(ev_recon_done, stream));
         // reference bookkeeping, state.rs:464-483
         unsynced_submits++;
@@ -273,13 +294,11 @@ struct h263mi_batch {
         return H263MI_OK;
     }
 
-    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
+    PostArgs post_args(int set, uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes) const
     {
-        if (cur < 0) return H263MI_ERR_NO_PICTURE;
-        if (strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
         PostArgs a{};
         a.L = L;
-        a.frames = frames[cur];
+        a.frames = frames[set];
         a.rgba = d_rgba;
         a.planes_out = d_planes;
         a.n_pictures = n;
@@ -287,6 +306,27 @@ struct h263mi_batch {
         a.tiles_x = post_tiles_x(L);
         a.tiles_y = post_tiles_y(L);
         a.luma_only = 0;
+        return a;
+    }
+
+    // the deferred post-processing of pipeline mode, as a launch of its own
+    int flush_pending()
+    {
+        if (!pending.valid) return H263MI_OK;
+        pending.valid = false;
+        const PostArgs a = post_args(pending.set, pending.strength, pending.rgba, pending.planes);
+        RC_TRY(time_begin(1));
+        HIP_TRY(launch_post(a, stream));
+        RC_TRY(time_end(1));
+        return H263MI_OK;
+    }
+
+    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
+    {
+        if (cur < 0) return H263MI_ERR_NO_PICTURE;
+        if (strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
+        RC_TRY(flush_pending());
+        const PostArgs a = post_args(cur, strength, d_rgba, d_planes);
         if (overlap_post) HIP_TRY(hipStreamWaitEvent(post_stream, ev_recon_done, 0));
         RC_TRY(time_begin(1));
         HIP_TRY(launch_post(a, stream_of(1)));
@@ -297,6 +337,7 @@ struct h263mi_batch {
 
     int sync()
     {
+        RC_TRY(flush_pending());
         if (overlap_post) HIP_TRY(hipStreamSynchronize(post_stream));
         HIP_TRY(hipMemcpyAsync(h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -361,7 +402,8 @@ static int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi
     b->device = dev;
     b->stream = cfg ? (hipStream_t)cfg->stream : nullptr;
     int rc = H263MI_OK;
-    if (cfg && (cfg->flags & H263MI_CFG_OVERLAP_POST)) {
+    b->pipeline_post = cfg && (cfg->flags & H263MI_CFG_PIPELINE_POST);
+    if (cfg && (cfg->flags & H263MI_CFG_OVERLAP_POST) && !b->pipeline_post) {
         b->overlap_post = true;
         if (hipStreamCreateWithFlags(&b->post_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_recon_done, hipEventDisableTiming) != hipSuccess ||
@@ -533,6 +575,23 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
     DeviceGuard g(b->device);
     b->coeff_checked = coeff_pool_blocks != 0;
     b->coeff_pool_blocks = coeff_pool_blocks;
+    if (b->pipeline_post) {
+        // this picture's reconstruction and the previous picture's post-processing in one launch; this picture's
+        // post-processing waits for the next call (or the next sync)
+        if (b->pending.valid && b->pending.set == b->cur) {
+            const PostArgs pa = b->post_args(b->pending.set, b->pending.strength, b->pending.rgba, b->pending.planes);
+            b->pending.valid = false;
+            RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base, &pa));
+        } else {
+            RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
+        }
+        b->pending.valid = d_rgba || d_deblocked;
+        b->pending.strength = strength;
+        b->pending.rgba = d_rgba;
+        b->pending.planes = d_deblocked;
+        b->pending.set = b->cur;
+        return H263MI_OK;
+    }
     RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
     if (!d_rgba && !d_deblocked) return H263MI_OK;
     return b->render(strength, d_rgba, d_deblocked);
@@ -787,9 +846,12 @@ int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out)
         if (r.second == 0) {
             out->recon_ms += ms;
             out->recon_launches++;
-        } else {
+        } else if (r.second == 1) {
             out->post_ms += ms;
             out->post_launches++;
+        } else {
+            out->frame_ms += ms;
+            out->frame_launches++;
         }
     }
     b->ev_ranges.clear();
@@ -810,7 +872,7 @@ int h263mi_state_new(uint32_t decoder_options, const h263mi_backend_cfg *cfg, h2
     s->options = decoder_options;
     if (cfg) s->cfg = *cfg;
     s->cfg.device_id = dev;
-    s->cfg.flags &= ~H263MI_CFG_OVERLAP_POST;    // batches only: h263mi_render_rgba copies back on the main stream
+    s->cfg.flags &= ~(H263MI_CFG_OVERLAP_POST | H263MI_CFG_PIPELINE_POST);   // batches only: h263mi_render_rgba copies back on the main stream
     *out = s;
     return H263MI_OK;
 }

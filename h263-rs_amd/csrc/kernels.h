@@ -26,7 +26,16 @@ struct ExpandArgs {
 };
 
 hipError_t launch_expand(const ExpandArgs &args, hipStream_t stream);
+// geometry of the merged launch (k_frame), made by its launcher
+struct FrameGeom {
+    uint32_t groups;            // groups of 32 luma rows per picture
+    uint32_t recon_per_group;   // reconstruction sub-tiles (waves) per group: 4 per 8x2-macroblock tile
+    uint32_t post_per_group;    // post tiles (waves) per group
+    uint32_t inv_per_group;     // ceil(2^32 / (recon_per_group + post_per_group))
+};
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream);
+// k_recon over `rargs` and k_post over `pargs` (same number of pictures, same picture size) as ONE launch
+hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream);
 hipError_t launch_post(const PostArgs &args, hipStream_t stream);
 hipError_t launch_synth_headers(const SynthArgs &args, hipStream_t stream);
 hipError_t launch_synth_coeffs(const SynthArgs &args, hipStream_t stream);

@@ -45,28 +45,9 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 // k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
 // workgroup, tiles taken in XCD-aware order (see k_post below).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
+// One wave's share of the reconstruction: the sub-tile(s) at `p` (RECON_HALVES of them, p.half counting up).
+__device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int lane, WavePos p)
 {
-    __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
-    ReconWave &s = waves[wave];
-    // grid.y = picture; grid.x walks the picture's (tile, macroblock row[, half]) list, RECON_WAVES entries per
-    // workgroup, in XCD-aware order (gridDim.x is a multiple of 8, so blockIdx.x & 7 names the XCD for every
-    // picture).  With RECON_HALVES == 2 a wave does both halves of its macroblock row one after the other.
-    // No integer division on the device: the only one left, by tiles_x, is a multiply-high with a host-made reciprocal.
-    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES / RECON_WAVES;
-    const uint32_t upp = a.tiles_x * a.tiles_y * kUnitsPerTile;           // work items of one picture
-    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
-    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
-    if (t >= chunk || g >= upp) return;
-    const uint32_t tile = g / kUnitsPerTile;                               // power of two
-    const int tw = ((int)(g % kUnitsPerTile) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
-    const uint32_t tile_y = div_tiles_x(tile, a.tiles_x, a.inv_tiles_x), tile_x = tile - tile_y * a.tiles_x;
-    WavePos p;
-    p.pic = (int)blockIdx.y;
-    p.mbx0 = (int)tile_x * TILE_MBX;
-    p.mby = (int)tile_y * TILE_MBY + (tw >> 1);
-    p.half = tw & 1;
     if (p.mby >= (int)a.L.mbh) return;
     p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
 
@@ -138,6 +119,31 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     }
 }
 
+__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
+{
+    __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
+    // grid.y = picture; grid.x walks the picture's (tile, macroblock row[, half]) list, RECON_WAVES entries per
+    // workgroup, in XCD-aware order (gridDim.x is a multiple of 8, so blockIdx.x & 7 names the XCD for every
+    // picture).  With RECON_HALVES == 2 a wave does both halves of its macroblock row one after the other.
+    // No integer division on the device: the only one left, by tiles_x, is a multiply-high with a host-made reciprocal.
+    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES / RECON_WAVES;
+    const uint32_t upp = a.tiles_x * a.tiles_y * kUnitsPerTile;           // work items of one picture
+    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
+    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
+    if (t >= chunk || g >= upp) return;
+    const uint32_t tile = g / kUnitsPerTile;                               // power of two
+    const int tw = ((int)(g % kUnitsPerTile) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
+    const uint32_t tile_y = div_tiles_x(tile, a.tiles_x, a.inv_tiles_x), tile_x = tile - tile_y * a.tiles_x;
+    WavePos p;
+    p.pic = (int)blockIdx.y;
+    p.mbx0 = (int)tile_x * TILE_MBX;
+    p.mby = (int)tile_y * TILE_MBY + (tw >> 1);
+    p.half = tw & 1;
+    p.cbase = 0;
+    recon_wave(a, waves[wave], lane, p);
+}
+
 // ceil(2^32 / d): n / d == mul_hi(n, r) for n * d < 2^32
 static uint32_t reciprocal_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
 
@@ -199,11 +205,26 @@ __device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s,
     post_strip<FETCH_AHEAD>(a, s, pf1, lane, sx, sy + 1, pic);
 }
 
+// One wave's share of the post-processing: the 128x32 tile (sx, ty) of picture `pic` = 4 strips.
+// No workgroup barrier anywhere: the wave owns its strips from load to store.  Two strips are always in flight ahead
+// of the one being filtered.  Strips past the bottom of the picture are processed like any other (clamped loads, no
+// rows to store), which keeps the code straight-line and the number of loads fixed, so each wait is an exact
+// s_waitcnt vmcnt(8).
+__device__ __forceinline__ void post_wave(const PostArgs &a, PostStrip &s, int lane, int sx, int ty, int pic)
+{
+    if (ty >= (int)a.tiles_y) return;
+    const int sy0 = ty * POST_STRIPS;
+    PostFetch pf0, pf1;
+    post_phase_fetch(a, pf0, lane, sx, sy0, pic);
+    post_phase_fetch(a, pf1, lane, sx, sy0 + 1, pic);
+    post_strip_pair<true>(a, s, pf0, pf1, lane, sx, sy0, pic);          // strips 0,1; queues the loads of 2,3
+    post_strip_pair<false>(a, s, pf0, pf1, lane, sx, sy0 + 2, pic);     // strips 2,3
+}
+
 __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 {
     __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
-    PostStrip &s = strips[wave];
     // one wave = one 128x32 tile = 4 strips; a workgroup = 4 vertically adjacent tiles (a 128x128 block), and
     // workgroups follow each other along x in the XCD-ordered list.  Horizontal neighbours -- which share the
     // cache lines the 4-pixel tile offset straddles -- are thus in different workgroups, start at slightly
@@ -222,18 +243,61 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     const int pic = (int)blockIdx.y;
     const uint32_t gy = div_tiles_x(wg, a.tiles_x, a.inv_tiles_x);
     const int sx = (int)(wg - gy * a.tiles_x), ty = (int)gy * POST_GROUP + gw;
-    if (ty >= (int)a.tiles_y) return;
-    const int sy0 = ty * POST_STRIPS;
-    // no workgroup barrier anywhere: the wave owns its strips from load to store.  All loads of the
-    // tile are queued first; each strip then waits only for its own.
-    // Two strips are always in flight ahead of the one being filtered.  Strips past the bottom of the
-    // picture are processed like any other (clamped loads, no rows to store), which keeps the code
-    // straight-line and the number of loads fixed, so each wait is an exact s_waitcnt vmcnt(8).
-    PostFetch pf0, pf1;
-    post_phase_fetch(a, pf0, lane, sx, sy0, pic);
-    post_phase_fetch(a, pf1, lane, sx, sy0 + 1, pic);
-    post_strip_pair<true>(a, s, pf0, pf1, lane, sx, sy0, pic);          // strips 0,1; queues the loads of 2,3
-    post_strip_pair<false>(a, s, pf0, pf1, lane, sx, sy0 + 2, pic);     // strips 2,3
+    post_wave(a, strips[wave], lane, sx, ty, pic);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_frame: reconstruction of picture f and post-processing of picture f - 1 of every stream in ONE launch
+// (the frame-pipelined form of h263mi_batch_decode).  Both halves read the same frame set -- k_recon as its
+// reference picture, k_post as the picture to filter and convert -- and neither writes it, so they need no ordering
+// between them.  The work list of a picture is cut into GROUPS of 32 luma rows: the 4 * rtx reconstruction
+// sub-tiles of two macroblock rows, then the ptx post tiles over (almost) the same rows; the list is dealt to the 8
+// XCDs in contiguous chunks as in the two kernels above.  Waves that read the same rows of the same picture thus run
+// at the same time on the same XCD: the planes are fetched from HBM once per frame instead of twice, and waves
+// bound by arithmetic and address work (reconstruction) share every CU with waves bound by stores (RGBA).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg)
+{
+    __shared__ __attribute__((aligned(16))) union { ReconWave r; PostStrip p; } lds;
+    const int lane = threadIdx.x & 63;
+    const uint32_t per_group = fg.recon_per_group + fg.post_per_group;
+    const uint32_t upp = fg.groups * per_group;
+    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
+    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
+    if (t >= chunk || g >= upp) return;
+    const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group), r = g - group * per_group;
+    if (r < fg.recon_per_group) {
+        WavePos p;
+        p.pic = (int)blockIdx.y;
+        p.mbx0 = (int)(r >> 2) * TILE_MBX;
+        p.mby = (int)group * TILE_MBY + (int)((r >> 1) & 1);
+        p.half = (int)(r & 1);
+        p.cbase = 0;
+        recon_wave(ra, lds.r, lane, p);
+    } else {
+        post_wave(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group, (int)blockIdx.y);
+    }
+}
+
+hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream)
+{
+    if (!rargs.n_pictures) return hipSuccess;
+    if (rargs.n_pictures != pargs.n_pictures || rargs.n_pictures > 65535) return hipErrorInvalidValue;
+    static_assert(RECON_WAVES == 1 && RECON_HALVES == 1 && POST_WAVES == 1, "k_frame is written for single-wave workgroups");
+    FrameGeom fg;
+    fg.recon_per_group = rargs.tiles_x * TILE_WAVES;
+    fg.post_per_group = pargs.tiles_x;
+    fg.groups = rargs.tiles_y > pargs.tiles_y ? rargs.tiles_y : pargs.tiles_y;
+    const uint32_t per_group = fg.recon_per_group + fg.post_per_group;
+    if ((uint64_t)fg.groups * per_group >= (1u << 24)) return hipErrorInvalidValue;
+    fg.inv_per_group = reciprocal_u32(per_group);
+    ReconArgs ra = rargs;
+    PostArgs pa = pargs;
+    ra.inv_tiles_x = reciprocal_u32(rargs.tiles_x);
+    pa.inv_tiles_x = reciprocal_u32(pargs.tiles_x);
+    const uint32_t chunk = (fg.groups * per_group + 7) / 8;
+    hipLaunchKernelGGL(k_frame, dim3(chunk * 8, rargs.n_pictures), dim3(64), 0, stream, ra, pa, fg);
+    return hipGetLastError();
 }
 
 hipError_t launch_post(const PostArgs &args, hipStream_t stream)

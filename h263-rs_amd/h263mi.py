@@ -100,7 +100,8 @@ class FrameView(C.Structure):
 
 class KernelTimes(C.Structure):
     _fields_ = [("recon_ms", C.c_double), ("recon_launches", C.c_uint32), ("pad0", C.c_uint32),
-                ("post_ms", C.c_double), ("post_launches", C.c_uint32), ("pad1", C.c_uint32)]
+                ("post_ms", C.c_double), ("post_launches", C.c_uint32), ("pad1", C.c_uint32),
+                ("frame_ms", C.c_double), ("frame_launches", C.c_uint32), ("pad2", C.c_uint32)]
 
 
 def build(force=False):
@@ -376,9 +377,9 @@ class DeviceBuffer:
 class Batch:
     """N independent streams advancing in lock step on one GPU (h263mi_batch_*)."""
 
-    def __init__(self, n_streams, width, height, device_id=0, stream=None, overlap_post=False):
+    def __init__(self, n_streams, width, height, device_id=0, stream=None, overlap_post=False, pipeline_post=False):
         self.n, self.width, self.height, self.device_id = n_streams, width, height, device_id
-        self._cfg = BackendCfg(device_id, 1 if overlap_post else 0, stream)
+        self._cfg = BackendCfg(device_id, (1 if overlap_post else 0) | (2 if pipeline_post else 0), stream)
         self._h = C.c_void_p()
         _check(lib().h263mi_batch_create(n_streams, width, height, C.byref(self._cfg), C.byref(self._h)),
                "batch_create")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define H263MI_ABI_VERSION 1
+#define H263MI_ABI_VERSION 2
 
 /* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
 #define H263MI_OK                                  0
@@ -136,6 +136,13 @@ typedef struct h263mi_picture_desc {
  * flags: H263MI_CFG_OVERLAP_POST (batches only): h263mi_batch_render_rgba runs on a second, internal stream so
  * that post-processing picture i overlaps reconstructing picture i+1; h263mi_batch_sync waits for both. */
 #define H263MI_CFG_OVERLAP_POST 0x1u
+/* H263MI_CFG_PIPELINE_POST (batches only): h263mi_batch_decode defers the deblock + BT.601 of a picture to the launch
+ * that reconstructs the NEXT picture of the batch: one launch (k_frame) then reads the frame set once for both
+ * purposes -- as the reference picture of the new pictures and as the pictures to filter and convert.  The output
+ * buffers handed to h263mi_batch_decode are complete after the next h263mi_batch_sync (or after the next call that
+ * renders or decodes on this batch has been followed by a sync); a consumer that reads them in stream order must
+ * call h263mi_batch_sync first.  Results are identical to the immediate mode. */
+#define H263MI_CFG_PIPELINE_POST 0x2u
 typedef struct h263mi_backend_cfg {
     int32_t  device_id;
     uint32_t flags;
@@ -328,8 +335,9 @@ int h263mi_batch_copy_yuv(h263mi_batch *b, uint32_t stream, uint8_t *y, uint8_t 
 
 /* Per-kernel device time between begin/end, measured with hipEvents on the batch stream. */
 typedef struct h263mi_kernel_times {
-    double   recon_ms;  uint32_t recon_launches;  uint32_t pad0;
-    double   post_ms;   uint32_t post_launches;   uint32_t pad1;
+    double   recon_ms;  uint32_t recon_launches;  uint32_t pad0;   /* k_recon on its own */
+    double   post_ms;   uint32_t post_launches;   uint32_t pad1;   /* k_post on its own */
+    double   frame_ms;  uint32_t frame_launches;  uint32_t pad2;   /* k_frame: both in one launch (H263MI_CFG_PIPELINE_POST) */
 } h263mi_kernel_times;
 int h263mi_batch_timing_begin(h263mi_batch *b);
 int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out);

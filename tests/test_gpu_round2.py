@@ -277,3 +277,63 @@ def test_batch_decode_next_pictures_from_bitstreams():
         b.decode_next_pictures([other] * n)
     assert e.value.code == h263mi.ERR_PICTURE_FORMAT_INVALID
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# H263MI_CFG_PIPELINE_POST: reconstruction of picture f and post-processing of picture f-1 in one launch (k_frame)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,n", [(176, 144, 3), (100, 60, 2), (33, 17, 1), (352, 288, 2), (1920, 1080, 2), (64, 36, 2)])
+def test_pipelined_batch_gives_the_same_pictures(w, h, n):
+    """every picture's planes, RGBA and filtered planes against the oracle; the mode mixes with the immediate calls
+    (submit / render_rgba), with reset, and an I picture in the middle of the chain"""
+    b = h263mi.Batch(n, w, h, pipeline_post=True)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    n_frames = 6
+    d_rgba = [h263mi.DeviceBuffer(n * w * h * 4) for _ in range(n_frames)]
+    d_planes = [h263mi.DeviceBuffer(n * (w * h + 2 * cw * ch)) for _ in range(n_frames)]
+    refs = [None] * n
+    want = []
+    for f in range(n_frames):
+        intra = f in (0, 4)
+        mbs_all, co_all, base, at = [], [], [], 0
+        for s in range(n):
+            if intra:
+                m, c = recgen.intra_picture(w, h, seed=11 * s + f)
+            else:
+                m, c = recgen.inter_picture(w, h, seed=100 * f + s, mv_range=40, p_4v=0.3, p_intra=0.1, p_coded=0.4, quant=8)
+            rc, refs[s] = orc.decode_picture(w, h, m, c, None if intra else refs[s])
+            assert rc == 0
+            mbs_all.append(simlib_pad(m, w, h))
+            co_all.append(c)
+            base.append(at)
+            at += len(c)
+        strength = (5, 0, 12, 1, 7, 3)[f]
+        want.append([(refs[s], strength) for s in range(n)])
+        d_m = _upload(np.concatenate(mbs_all))
+        d_c = _upload(np.concatenate(co_all) if at else np.zeros((1, 64), np.int16))
+        d_b = _upload(np.array(base, np.uint64))
+        pt = h263mi.PICTURE_I if intra else h263mi.PICTURE_P
+        if f == 3:                                               # the immediate calls in the middle of the pipeline
+            b.submit(pt, d_m.ptr, d_c.ptr, d_b.ptr)
+            b.render_rgba(strength, d_rgba[f].ptr, d_planes[f].ptr)
+        else:
+            b.decode(pt, d_m.ptr, d_c.ptr, d_b.ptr, max(at, 1), strength, d_rgba[f].ptr, d_planes[f].ptr)
+    b.sync()
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), refs[s], "last picture, stream %d" % s)
+    ny, nc = w * h, cw * ch
+    for f in range(n_frames):
+        rgba, planes = d_rgba[f].download(), d_planes[f].download()
+        for s in range(n):
+            ref, strength = want[f][s]
+            filt = ref if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(ref, (w, cw, cw)))
+            assert (rgba[s * ny * 4:(s + 1) * ny * 4] == orc.yuv420_to_rgba(*filt, w)).all(), (f, s)
+            off = s * (ny + 2 * nc)
+            got = (planes[off:off + ny], planes[off + ny:off + ny + nc], planes[off + ny + nc:off + ny + 2 * nc])
+            assert_planes_equal(got, filt, "filtered planes frame %d stream %d" % (f, s))
+    b.close()
+
+
+def simlib_pad(mbs, w, h):
+    import simlib
+    return simlib.pad_records(mbs, w, h)

@@ -18,7 +18,7 @@ for path in sorted(glob.glob(os.path.join(root, "*", "**", "*counter_collection.
     rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
     for row in rows:
         name = row.get("Kernel_Name", "").split("(")[0]
-        if "k_recon" not in name and "k_post" not in name:
+        if "k_recon" not in name and "k_post" not in name and "k_frame" not in name:
             continue
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name in sorted(acc):

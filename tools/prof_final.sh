@@ -24,7 +24,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r.get("Dispatch_Id", 0)))
         for row in rows:
             name = row["Kernel_Name"].split("(")[0].split("::")[-1]
-            if name in ("k_recon", "k_post"):
+            if name in ("k_recon", "k_post", "k_frame"):
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 traffic = {}
 for k, v in acc.items():

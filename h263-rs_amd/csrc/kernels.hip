@@ -45,6 +45,35 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 // k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
 // workgroup, tiles taken in XCD-aware order (see k_post below).
 // ---------------------------------------------------------------------------------------
+// One IDCT round of a wave: 8 blocks, 8 lanes each.
+template <bool FIRST>
+__device__ __forceinline__ void recon_round(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
+                                            int round, const WaveMasks &km)
+{
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    RowIn ri;
+    ISA_MARK("round_begin");
+    recon_phase_idct_load(a, s, f, ln, p, FIRST ? 0 : round, ri, km);
+    ISA_MARK("idct_load_end");
+    // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
+    const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
+                        (__ballot(ri.w[3] != 0) ? 8u : 0u);
+    const RowClass rc = recon_row_class(ri, ln);
+    const uint64_t rows_any = __ballot(rc.any), cols_any = __ballot(rc.beyond_first);      // bit slot*8 + row
+    wave_fence();                           // the column pass of the previous round has read tbuf
+    recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm), cols_any);
+    uint32_t rows_mask = (uint32_t)rows_any | (uint32_t)(rows_any >> 32);
+    rows_mask |= rows_mask >> 16;
+    rows_mask |= rows_mask >> 8;
+    const bool any_special = __ballot(recon_block_is_special(ri, ln, rows_any, cols_any)) != 0;
+    asm volatile("" : "+v"(ln));
+    wave_fence();                           // the row pass results are in LDS
+    ISA_MARK("idct_rows_end");
+    recon_phase_idct_cols(s, ri, ln, rows_from_mask(rows_mask & 0xffu), rows_any, cols_any, any_special);
+    ISA_MARK("idct_cols_end");
+}
+
 // One wave's share of the reconstruction: the sub-tile(s) at `p` (RECON_HALVES of them, p.half counting up).
 __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int lane, WavePos p)
 {
@@ -81,30 +110,13 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
         const int n_active = recon_n_active(km);
         ISA_MARK("fetch_end");
         PHASE_MARK(2);
+        // The first round is peeled off the loop: its coefficient row was requested by the fetch phase, ahead of the
+        // reference rows, and straight-line code is what lets the compiler wait for exactly that load
+        // (s_waitcnt vmcnt(6)) and leave the six reference loads in flight under the IDCT.  Inside the loop the
+        // per-round coefficient load makes every wait a vmcnt(0).
+        if (n_active > 0) recon_round<true>(a, s, f, ln, p, 0, km);
 #pragma unroll 1
-        for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
-            asm volatile("" : "+v"(ln));
-            RowIn ri;
-            ISA_MARK("round_begin");
-            recon_phase_idct_load(a, s, f, ln, p, round, ri, km);
-            ISA_MARK("idct_load_end");
-            // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
-            const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
-                                (__ballot(ri.w[3] != 0) ? 8u : 0u);
-            const RowClass rc = recon_row_class(ri, ln);
-            const uint64_t rows_any = __ballot(rc.any), cols_any = __ballot(rc.beyond_first);      // bit slot*8 + row
-            wave_fence();                           // the column pass of the previous round has read tbuf
-            recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm), cols_any);
-            uint32_t rows_mask = (uint32_t)rows_any | (uint32_t)(rows_any >> 32);
-            rows_mask |= rows_mask >> 16;
-            rows_mask |= rows_mask >> 8;
-            const bool any_special = __ballot(recon_block_is_special(ri, ln, rows_any, cols_any)) != 0;
-            asm volatile("" : "+v"(ln));
-            wave_fence();                           // the row pass results are in LDS
-            ISA_MARK("idct_rows_end");
-            recon_phase_idct_cols(s, ri, ln, rows_from_mask(rows_mask & 0xffu), rows_any, cols_any, any_special);
-            ISA_MARK("idct_cols_end");
-        }
+        for (int round = 1; round * ROUND_BLOCKS < n_active; round++) recon_round<false>(a, s, f, ln, p, round, km);
         PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
 #if defined(H263MI_PROFILE_PHASES)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -97,10 +97,10 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
         km.valid = recon_valid_mask(a, p);
         wave_fence();                               // the records are in LDS
         const TaskInfo ti = recon_phase_mark(a, s, ln, p, km.valid, recon_block_limit(a, p));
-        const uint64_t act64 = __ballot(ti.active), inter64 = __ballot(ti.inter);
+        const uint64_t act64 = __ballot(ti.active != 0), inter64 = __ballot(ti.inter != 0);
         km.act = (uint32_t)act64;                   // bits 0..23
         km.inter = (uint32_t)(inter64 >> WAVE_TASKS) & 0xffu;
-        recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index) != 0);
+        recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index != 0) != 0);
         recon_phase_compact(s, ln, ti, km.act);
         wave_fence();                               // descriptors and chroma vectors are in LDS
         ISA_MARK("mark_end");

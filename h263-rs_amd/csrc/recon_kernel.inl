@@ -77,9 +77,9 @@ static_assert(sizeof(MbRecord) == 32 && offsetof(MbRecord, mv) == 4 && offsetof(
 constexpr uint32_t NO_COEFFS = 0xffffffffu;
 struct TaskInfo {
     uint32_t d0, d1;
-    bool active;                               // the block goes through the IDCT
-    bool inter;                                // (macroblock lanes) inside the picture and inter coded
-    bool bad_index;                            // coded block outside the coefficient pool
+    uint32_t active;                           // 1: the block goes through the IDCT
+    uint32_t inter;                            // 1: (macroblock lanes) inside the picture and inter coded
+    uint32_t bad_index;                        // 1: coded block outside the coefficient pool
 };
 H263_HD uint32_t desc_quant(uint32_t d1) { return d1 & 0xffu; }
 H263_HD uint32_t desc_level(uint32_t d1) { return (d1 >> 8) & 0x7ffu; }
@@ -359,12 +359,13 @@ H263_DEV uint32_t recon_valid_mask(const ReconArgs &a, const WavePos &p)
 // picture's first block is p.cbase, and block offsets are 32-bit byte offsets (2^25 blocks of 128 bytes).
 H263_DEV uint32_t recon_block_limit(const ReconArgs &a, const WavePos &p)
 {
-    uint64_t lim = 1u << 25;
-    if (a.coeff_checked) {
-        const uint64_t left = a.coeff_pool_blocks > p.cbase ? a.coeff_pool_blocks - p.cbase : 0;
-        if (left < lim) lim = left;
-    }
-    return (uint32_t)lim;
+    if (!a.coeff_checked) return 1u << 25;
+    // min(pool - cbase, 2^25), 0 when the picture's base lies beyond the pool; in 32-bit pieces so that it stays on
+    // the scalar unit (both values are far below 2^63: the sign of the difference tells which is larger)
+    const uint64_t left = a.coeff_pool_blocks - p.cbase;
+    const uint32_t hi = (uint32_t)(left >> 32), lo = (uint32_t)left;
+    if ((int32_t)hi < 0) return 0u;
+    return (hi || lo > (1u << 25)) ? (1u << 25) : lo;
 }
 
 H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p)
@@ -389,37 +390,49 @@ H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const
 H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, const WavePos &p, uint32_t valid_mask,
                                    uint32_t block_limit)
 {
-    const bool is_task = lane < WAVE_TASKS, is_mb = lane >= WAVE_TASKS && lane < WAVE_TASKS + TILE_MBX;
-    const int m = lane < 16 ? (lane >> 1) : (lane & 7);
-    const uint32_t blk = lane < 16 ? (uint32_t)(p.half * 2 + (lane & 1)) : (uint32_t)(4 + p.half);
+    // Decisions are 0 / 1 integers combined with shifts, ands and ors -- the 2-cycle VALU instructions; written with
+    // bool / ?: the same logic compiles to compares and selects at twice the price each (profiles/README.md).
+    const uint32_t ln = (uint32_t)lane;
+    const uint32_t is_task = (ln - WAVE_TASKS) >> 31;                        // lane < 24
+    const uint32_t is_mb = ((ln - WAVE_TASKS) < (uint32_t)TILE_MBX) ? 1u : 0u;
+    const uint32_t luma_task = (ln - 16u) >> 31;                              // lane < 16
+    const uint32_t m = (ln >> luma_task) & 7u;                                // lane >> 1 for luma tasks, lane & 7 else
+    const uint32_t blk = luma_task ? (uint32_t)(p.half * 2) + (ln & 1u) : (uint32_t)(4 + p.half);
     const uint32_t *r = s.rec[m];
     const uint32_t w0 = r[0], w7 = r[7], w5 = r[5], w6 = r[6], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4];
 
-    const uint32_t mb_type = w0 & 0xffu, cbpkill = w0 >> 16;
-    const bool valid = (valid_mask >> m) & 1u;
-    const bool intra = mb_type - 3u < 2u;                        // types.rs:661-663
-    const bool coded = (cbpkill >> blk) & 1u, killed = (cbpkill >> (8u + blk)) & 1u;
+    const uint32_t mb_type = w0 & 0xffu;
+    const uint32_t valid = (valid_mask >> m) & 1u;
+    // MacroblockType (types.rs:631-649, 653-663) as bit tables: intra = {3, 4}, inter = {0, 1, 2, 5}.  (A type above 5
+    // never comes out of a parser and is refused by every host entry point.)
+    const uint32_t intra = (0x18u >> (mb_type & 31u)) & 1u, inter_type = (0x27u >> (mb_type & 31u)) & 1u;
+    const uint32_t ck = (w0 >> 16) >> blk;                                    // bit 0: coded, bit 8: killed
+    const uint32_t coded = ck & 1u, killed = (ck >> 8) & 1u;
     const uint32_t dcb = (uint32_t)((((uint64_t)w6 << 32) | w5) >> (8u * blk)) & 0xffu;
-    const uint32_t level = dcb == 0xffu ? 1024u : dcb << 3;     // IntraDc::into_level, types.rs:955-961
+    const uint32_t dc_nonzero = (dcb + 255u) >> 8, dc_is_ff = (dcb + 1u) >> 8;
     // number of this block among the macroblock's coded blocks -> its place in the pool
-    const uint32_t idx = w7 + (uint32_t)popc32(cbpkill & ((1u << blk) - 1u) & 0x3fu);
-    const bool in_range = w7 < block_limit && idx < block_limit;
+    const uint32_t idx = w7 + (uint32_t)popc32((w0 >> 16) & ((1u << blk) - 1u) & 0x3fu);
+    const uint32_t worst = w7 > idx ? w7 : idx;                               // (idx may have wrapped)
+    const uint32_t in_range = worst < block_limit ? 1u : 0u;
 
     TaskInfo t;
     // coded & kill -> Zero (rle.rs:125-127); uncoded inter -> Zero; uncoded intra -> Dc(level)
-    t.active = is_task && valid && (coded ? !killed : (intra && dcb != 0));
-    t.bad_index = t.active && coded && !in_range;
-    t.d0 = (coded && in_range) ? idx << 7 : NO_COEFFS;
-    t.d1 = ((w0 >> 8) & 0xffu) | (level << 8) | ((intra ? 1u : 0u) << 19) | ((uint32_t)lane << 20);
-    // which macroblocks take a prediction from the reference picture (gather.rs:136-149; types.rs:653-658)
-    t.inter = is_mb && valid && !intra && mb_type < 6u;
+    t.active = is_task & valid & ((coded & (killed ^ 1u)) | ((coded ^ 1u) & intra & dc_nonzero));
+    t.bad_index = t.active & coded & (in_range ^ 1u);
+    t.d0 = (idx << 7) | (0u - ((coded & in_range) ^ 1u));                    // NO_COEFFS unless coded and in range
+    // IntraDc::into_level (types.rs:955-961): code << 3, 0xff -> 1024; here already shifted into its descriptor field
+    const uint32_t level8 = (dcb << 11) ^ ((0u - dc_is_ff) & ((2040u ^ 1024u) << 8));
+    t.d1 = ((w0 >> 8) & 0xffu) | level8 | ((0x18u << 19 >> (mb_type & 31u)) & (1u << 19)) | (ln << 20);
+    (void)intra;
+    // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
+    t.inter = is_mb & valid & inter_type;
 
     // gather.rs:182 / types.rs:759-768: chroma vector from the i16 sum of the four luma vectors, both components at
-    // once in the two halves of a dword.  s = sum, whole = (s >> 4) << 1, frac = s & 15,
+    // once in the two halves of a dword.  s = sum, whole = (s >> 4) << 1 = (s >> 3) & ~1, frac = s & 15,
     // result = whole + (frac > 2) + (frac >= 14) = whole + ((frac + 13) >> 4) + ((frac + 2) >> 4)
     {
         const uint32_t sum = pk_add_u16(pk_add_u16(w1, w2), pk_add_u16(w3, w4));
-        const uint32_t whole = pk_lshl_u16(pk_ashr_i16(sum, 4), 1);
+        const uint32_t whole = pk_ashr_i16(sum, 3) & 0xfffefffeu;
         const uint32_t frac = sum & 0x000f000fu;
         const uint32_t up = (((frac + 0x000d000du) >> 4) & 0x00010001u) + (((frac + 0x00020002u) >> 4) & 0x00010001u);
         if (is_mb) s.mvc[m] = pk_add_u16(whole, up);

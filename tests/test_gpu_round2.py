@@ -337,3 +337,73 @@ def test_pipelined_batch_gives_the_same_pictures(w, h, n):
 def simlib_pad(mbs, w, h):
     import simlib
     return simlib.pad_records(mbs, w, h)
+
+
+def test_pipelined_batch_rolls_back_a_rejected_picture():
+    """pipeline mode + a picture the device rejects: the batch goes back to the previous picture, whose deferred
+    post-processing has still been delivered, and carries on from there"""
+    w, h = 64, 48
+    b = h263mi.Batch(1, w, h, pipeline_post=True)
+    cw = (w + 1) // 2
+    im, ic = recgen.intra_picture(w, h, seed=21)
+    pm, pc = recgen.inter_picture(w, h, seed=22, p_coded=0.5)
+    bad = pm.copy()
+    bad[2]["cbp"] = 0x3F
+    bad[2]["coeff_index"] = len(pc) - 1
+    d_im, d_ic, d_pm, d_pc, d_bad = _upload(im), _upload(ic), _upload(pm), _upload(pc), _upload(bad)
+    rgba = [h263mi.DeviceBuffer(w * h * 4) for _ in range(3)]
+    b.decode(h263mi.PICTURE_I, d_im.ptr, d_ic.ptr, None, len(ic), 5, rgba[0].ptr)
+    b.decode(h263mi.PICTURE_P, d_bad.ptr, d_pc.ptr, None, len(pc), 5, rgba[1].ptr)     # launches I's post-processing too
+    with pytest.raises(h263mi.H263Error) as e:
+        b.sync()
+    assert e.value.code == h263mi.ERR_INVALID_ARGUMENT
+    rc, ref = orc.decode_picture(w, h, im, ic, None)
+    filt = tuple(orc.deblock(p, pw, 5) for p, pw in zip(ref, (w, cw, cw)))
+    # the I picture's deferred post-processing ran inside the launch that reconstructed the rejected picture
+    assert (rgba[0].download() == orc.yuv420_to_rgba(*filt, w)).all()
+    # two pictures were in flight since the last sync, so the batch cannot tell which one was rejected: none survives
+    with pytest.raises(h263mi.H263Error) as e:
+        b.copy_yuv(0)
+    assert e.value.code == h263mi.ERR_NO_PICTURE
+    # with a sync between them, the rejected picture alone is dropped
+    b.decode(h263mi.PICTURE_I, d_im.ptr, d_ic.ptr, None, len(ic), 5, rgba[0].ptr)
+    b.sync()
+    b.decode(h263mi.PICTURE_P, d_bad.ptr, d_pc.ptr, None, len(pc), 5, rgba[1].ptr)
+    with pytest.raises(h263mi.H263Error):
+        b.sync()
+    assert_planes_equal(b.copy_yuv(0), ref, "back to the I picture")
+    b.decode(h263mi.PICTURE_P, d_pm.ptr, d_pc.ptr, None, len(pc), 5, rgba[2].ptr)
+    b.sync()
+    rc, want = orc.decode_picture(w, h, pm, pc, ref)
+    assert_planes_equal(b.copy_yuv(0), want, "the valid P picture")
+    filt = tuple(orc.deblock(p, pw, 5) for p, pw in zip(want, (w, cw, cw)))
+    assert (rgba[2].download() == orc.yuv420_to_rgba(*filt, w)).all()
+    b.close()
+
+
+def test_batch_decode_next_pictures_mixed_types_and_lock_step():
+    """streams of one batch need not agree on the picture type: one stream restarts with an I picture while the
+    others continue with P pictures"""
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    w, h, n = 128, 96, 3
+    b = h263mi.Batch(n, w, h)
+    refs = [None] * n
+    for f in range(4):
+        datas = []
+        for s in range(n):
+            intra = f == 0 or (f == 2 and s == 1)
+            if intra:
+                mbs, co = recgen.intra_picture(w, h, seed=9 * s + f, max_level=60)
+                mbs = make_codable(mbs, 6, s, 0)
+            else:
+                mbs, co = recgen.inter_picture(w, h, seed=77 * f + s, mv_range=32, p_4v=0.2, p_coded=0.4, quant=6, max_level=60)
+                mbs = make_codable(mbs, 6, s + f, 1)
+            datas.append(enc.encode_picture(w, h, 0 if intra else 1, 6, mbs, co, temporal_reference=f))
+            rc, refs[s] = orc.decode_picture(w, h, mbs, co, None if intra else refs[s])
+            assert rc == 0
+        b.decode_next_pictures(datas, n_threads=2)
+        b.sync()
+        for s in range(n):
+            assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
+    b.close()

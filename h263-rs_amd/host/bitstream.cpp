@@ -113,18 +113,18 @@ int BitReader::read_umv(int &out)
 // ---------------------------------------------------------------------------------------------------
 // VLC tables
 // ---------------------------------------------------------------------------------------------------
-VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0)
+VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0), first_bits_(0), sub_mask_(0)
 {
     for (size_t i = 0; i < n; i++) {
         int l = (int)strlen(codes[i].bits);
         if (l > max_len_) max_len_ = l;
     }
-    lut_.assign((size_t)1 << max_len_, Slot{0, 0, 0, 0, 0});
     // (payloads fit the 8-bit slot fields: checked at compile time, see H263MI_TABLE)
-    // For every max_len_-bit pattern: the length at which a bit-by-bit walk of the code tree stops --
-    // either on a code word, or on the shortest prefix that no code word starts with (the tree's
+    // Flat table first.  For every max_len_-bit pattern: the length at which a bit-by-bit walk of the code tree
+    // stops -- either on a code word, or on the shortest prefix that no code word starts with (the tree's
     // "invalid" leaves).
-    for (uint32_t pat = 0; pat < lut_.size(); pat++) {
+    std::vector<Slot> flat((size_t)1 << max_len_, Slot{0, 0, 0, 0, 0});
+    for (uint32_t pat = 0; pat < flat.size(); pat++) {
         for (int l = 1; l <= max_len_; l++) {
             const uint32_t prefix = pat >> (max_len_ - l);
             bool is_code = false, extendable = false;
@@ -140,26 +140,44 @@ VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0)
                 }
             }
             if (is_code) {
-                lut_[pat] = Slot{(uint8_t)l, 1, (int8_t)codes[which].v0, (int8_t)codes[which].v1, (int8_t)codes[which].v2};
+                flat[pat] = Slot{(uint8_t)l, 1, (int8_t)codes[which].v0, (int8_t)codes[which].v1, (int8_t)codes[which].v2};
                 break;
             }
             if (!extendable) {
-                lut_[pat] = Slot{(uint8_t)l, 0, 0, 0, 0};
+                flat[pat] = Slot{(uint8_t)l, 0, 0, 0, 0};
                 break;
             }
+        }
+    }
+    // Two levels out of it: a prefix of first_bits_ bits whose walks all stop within the prefix gets its slot in the
+    // first level; the others get a sub-table of the remaining bits.
+    first_bits_ = max_len_ < 8 ? max_len_ : 8;
+    const int rest = max_len_ - first_bits_;
+    sub_mask_ = (1u << rest) - 1u;
+    first_.resize((size_t)1 << first_bits_);
+    for (uint32_t p = 0; p < first_.size(); p++) {
+        const Slot *run = &flat[(size_t)p << rest];
+        bool direct = true;
+        for (uint32_t k = 0; k <= sub_mask_; k++) direct = direct && run[k].len <= first_bits_;
+        first_[p].direct = direct ? 1 : 0;
+        first_[p].slot = run[0];
+        first_[p].sub = 0;
+        if (!direct) {
+            first_[p].sub = (uint16_t)second_.size();
+            second_.insert(second_.end(), run, run + sub_mask_ + 1);
         }
     }
 }
 
 int VlcTable::decode(BitReader &r, VlcHit &hit) const
 {
-    const Slot &s = lut_[r.peek_padded((uint32_t)max_len_)];
+    const Slot &s = lookup32(r.peek_padded(32));
     if (s.len > r.remaining()) {
         // the data ends inside the code word: the reference reads bit by bit and fails on the missing bit
         (void)r.skip_bits((uint32_t)r.remaining());
         return kEof;
     }
-    (void)r.skip_bits(s.len);
+    r.advance(s.len);
     hit.valid = s.valid != 0;
     hit.v0 = s.v0; hit.v1 = s.v1; hit.v2 = s.v2;
     return H263MI_OK;
@@ -194,66 +212,109 @@ H263MI_TABLE(mvd_table, kMvdCodes)
 // ---------------------------------------------------------------------------------------------------
 // block layer: parser/block.rs:670-755
 // ---------------------------------------------------------------------------------------------------
-int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, ParsedBlock &out)
+// `put(is_short, run, level)` receives the TCOEF events in bitstream order; `intradc` the INTRADC code of an intra
+// block.  On an error the reader is back where the block started (with_transaction, block.rs:682).
+namespace {
+template <class Sink>
+inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, uint8_t &intradc, Sink &&put)
 {
-    const size_t checkpoint = r.position();          // with_transaction (block.rs:682)
-    out.has_intradc = false;
-    out.intradc = 0;
-    out.n_tcoef = 0;
+    const size_t checkpoint = r.position();
     int rc = H263MI_OK;
     do {
         if (intra) {
             uint32_t code;
             if ((rc = r.read_u8(code)) != H263MI_OK) break;
             if (code == 0 || code == 128) { rc = H263MI_ERR_INVALID_INTRA_DC; break; }   // IntraDc::from_u8, types.rs:930-936
-            out.has_intradc = true;
-            out.intradc = (uint8_t)code;
+            intradc = (uint8_t)code;
         }
+        const VlcTable &table = tcoef_table();
         while (tcoef_present) {
+            if (r.remaining() >= 32) {
+                // Fast path: the longest TCOEF event -- escape (7) + Sorenson width flag + LAST + RUN (6) + LEVEL (11)
+                // = 26 bits -- lies inside one 32-bit window of data that is all there: one peek, no per-field
+                // end-of-data checks.  Same bits consumed and same errors as the field-by-field path below.
+                const uint32_t w = r.peek_padded(32);
+                const VlcTable::Slot &sl = table.lookup32(w);
+                uint32_t used = sl.len;
+                if (!sl.valid) { r.advance(used); rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
+                bool last;
+                if (sl.v0 >= 0) {
+                    const uint32_t sign = (w >> (31 - used)) & 1u;
+                    r.advance(used + 1);
+                    last = sl.v0 != 0;
+                    put(true, (int)sl.v1, sign ? -(int)sl.v2 : (int)sl.v2);
+                } else {                                 // ESCAPE (block.rs:689-724)
+                    uint32_t width = 8;
+                    if (sorenson && version == 1) {      // Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL
+                        width = ((w >> (31 - used)) & 1u) ? 11 : 7;
+                        used += 1;
+                    }
+                    last = (w >> (31 - used)) & 1u;
+                    used += 1;
+                    const int run = (int)((w >> (26 - used)) & 63u);
+                    used += 6;
+                    const uint32_t raw = (w >> (32 - used - width)) & ((1u << width) - 1u);
+                    used += width;
+                    const int level = (raw >> (width - 1)) ? (int)(raw | (~0u << width)) : (int)raw;   // reader.rs:176-187
+                    r.advance(used);
+                    if (level == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }
+                    put(false, run, level);
+                }
+                tcoef_present = !last;
+                continue;
+            }
+            // near the end of the data: field by field, every read checked
             VlcHit h;
-            if ((rc = tcoef_table().decode(r, h)) != H263MI_OK) break;
+            if ((rc = table.decode(r, h)) != H263MI_OK) break;
             if (!h.valid) { rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
             bool last;
-            int run, level;
-            bool is_short;
             if (h.v0 < 0) {                              // ESCAPE (block.rs:689-724)
                 uint32_t width = 8, v;
-                if (sorenson && version == 1) {          // Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL
+                if (sorenson && version == 1) {
                     if ((rc = r.read_bits(1, v)) != H263MI_OK) break;
                     width = v ? 11 : 7;
                 }
                 if ((rc = r.read_bits(1, v)) != H263MI_OK) break;
                 last = v == 1;
                 if ((rc = r.read_bits(6, v)) != H263MI_OK) break;
-                run = (int)v;
+                const int run = (int)v;
                 int32_t lv;
                 if ((rc = r.read_signed_bits(width, lv)) != H263MI_OK) break;
                 if (lv == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }
                 // (the reference's second check, `level == i16::MAX << level_width`, can never hold for a
                 // sign-extended LEVEL of that width: block.rs:708-715)
-                level = lv;
-                is_short = false;
+                put(false, run, (int)lv);
             } else {
                 uint32_t sign;
-                if ((rc = r.read_bits(1, sign)) != H263MI_OK) break;     // (VlcTable::decode_with_bit could fold this in)
+                if ((rc = r.read_bits(1, sign)) != H263MI_OK) break;
                 last = h.v0 != 0;
-                run = h.v1;
-                level = sign ? -(int)h.v2 : (int)h.v2;
-                is_short = true;
-            }
-            if (out.n_tcoef >= (int)(sizeof(out.tcoef) / sizeof(out.tcoef[0]))) {
-                // more events than a block can place: every further one lands beyond zigzag 63 anyway;
-                // keep parsing (the bitstream position matters) but stop storing
-            } else {
-                out.tcoef[out.n_tcoef].is_short = is_short;
-                out.tcoef[out.n_tcoef].run = (uint8_t)run;
-                out.tcoef[out.n_tcoef].level = (int16_t)level;
-                out.n_tcoef++;
+                put(true, (int)h.v1, sign ? -(int)h.v2 : (int)h.v2);
             }
             tcoef_present = !last;
         }
     } while (0);
     if (rc != H263MI_OK) r.rollback(checkpoint);
+    return rc;
+}
+}  // namespace
+
+int decode_block(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, ParsedBlock &out)
+{
+    out.has_intradc = false;
+    out.intradc = 0;
+    out.n_tcoef = 0;
+    const int capacity = (int)(sizeof(out.tcoef) / sizeof(out.tcoef[0]));
+    const int rc = decode_block_to(r, sorenson, version, intra, tcoef_present, out.intradc, [&](bool is_short, int run, int level) {
+        // more events than a block can place: every further one lands beyond zigzag 63 anyway; the parse goes on
+        // (the bitstream position matters) but nothing more is stored
+        if (out.n_tcoef >= capacity) return;
+        out.tcoef[out.n_tcoef].is_short = is_short;
+        out.tcoef[out.n_tcoef].run = (uint8_t)run;
+        out.tcoef[out.n_tcoef].level = (int16_t)level;
+        out.n_tcoef++;
+    });
+    out.has_intradc = intra && rc == H263MI_OK;
+    if (rc != H263MI_OK) out.intradc = 0;
     return rc;
 }
 
@@ -582,15 +643,17 @@ int16_t median3(int16_t self, int16_t mhs, int16_t rhs)
 }
 
 // predict_candidate (mvd_pred.rs:27-67); pv = vectors of the macroblocks decoded so far
-Mv predict_candidate(const std::vector<Mv> &pv /* 4 per MB */, const Mv cur[4], size_t mb_per_line, int index)
+// (`col`, `line`: position of the current macroblock, kept by the caller -- two 64-bit divisions per candidate
+// were a third of the time of a P picture)
+Mv predict_candidate(const std::vector<Mv> &pv /* 4 per MB */, const Mv cur[4], size_t mb_per_line, int index, size_t col,
+                     size_t line)
 {
-    const size_t current_mb = pv.size() / 4, col = current_mb % mb_per_line;
+    const size_t current_mb = pv.size() / 4;
     const Mv zero{0, 0};
     Mv mv1;
     if (index == 0 || index == 2) mv1 = col == 0 ? zero : pv[(current_mb - 1) * 4 + (size_t)index + 1];
     else mv1 = cur[index - 1];
 
-    const size_t line = current_mb / mb_per_line;
     const size_t last_line_mb = (line ? line - 1 : 0) * mb_per_line + col;
     Mv mv2;
     if (index <= 1) {
@@ -656,8 +719,16 @@ bool resync_ends_picture(BitReader &r, int &rc)
 int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, const ParserContext *ctx, ParsedPicture &out)
 {
     const bool want_dense = out.want_dense;
-    out = ParsedPicture();
-    out.want_dense = want_dense;
+    // (the vectors keep their capacity from one picture of a stream to the next: a 1080p I picture has a million
+    // events, and growing that vector from nothing costs as much as parsing a P picture)
+    out.desc = h263mi_picture_desc{};
+    out.mbs.clear();
+    out.coeffs.clear();
+    out.block_first_event.clear();
+    out.events.clear();
+    out.n_coded_blocks = 0;
+    out.bits_consumed = 0;
+    out.next = ParserContext();
     out.block_first_event.push_back(0);
     BitReader r(data, len);
     PictureHeader hdr;
@@ -703,6 +774,9 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     std::vector<Mv> predictor_vectors;             // 4 per decoded macroblock
     predictor_vectors.reserve(total * 4);
 
+    size_t mb_col = 0, mb_line = 0;                  // position of the macroblock being decoded
+    const VlcTable &t_mcbpc_i = mcbpc_i_table(), &t_mcbpc_p = mcbpc_p_table(), &t_cbpy = cbpy_table(), &t_mvd = mvd_table();
+    out.mbs.reserve(total);
     for (;;) {                                       // state.rs:193-417
         const size_t mb_checkpoint = r.position();   // decode_macroblock runs in a transaction (macroblock.rs:454)
         int mrc = H263MI_OK;
@@ -716,15 +790,15 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             if (hdr.picture_type != H263MI_PICTURE_I && (mrc = r.read_bits(1, cod)) != H263MI_OK) break;
             if (cod) { uncoded = true; break; }
             VlcHit h;
-            if (hdr.picture_type == H263MI_PICTURE_I) mrc = mcbpc_i_table().decode(r, h);
-            else if (hdr.picture_type == H263MI_PICTURE_P) mrc = mcbpc_p_table().decode(r, h);
+            if (hdr.picture_type == H263MI_PICTURE_I) mrc = t_mcbpc_i.decode(r, h);
+            else if (hdr.picture_type == H263MI_PICTURE_P) mrc = t_mcbpc_p.decode(r, h);
             else mrc = H263MI_ERR_UNIMPLEMENTED_DECODING;            // macroblock.rs:461-465
             if (mrc != H263MI_OK) break;
             if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_HEADER; break; }
             if (h.v0 < 0) { stuffing = true; break; }
             mb_type = h.v0; cb = h.v1; cr = h.v2;
             const bool intra = mb_type == H263MI_MB_INTRA || mb_type == H263MI_MB_INTRA_Q;
-            if ((mrc = cbpy_table().decode(r, h)) != H263MI_OK) break;
+            if ((mrc = t_cbpy.decode(r, h)) != H263MI_OK) break;
             if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS; break; }
             luma = intra ? h.v0 : (~h.v0 & 0xf);                     // macroblock.rs:479-489
             if (running_options & OPT_MODIFIED_QUANTIZATION) { mrc = H263MI_ERR_UNIMPLEMENTED_DECODING; break; }   // macroblock.rs:497-498
@@ -745,9 +819,9 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                         continue;
                     }
                     VlcHit hx, hy;                                   // decode_motion_vector (macroblock.rs:414-438)
-                    if ((mrc = mvd_table().decode(r, hx)) != H263MI_OK) break;
+                    if ((mrc = t_mvd.decode(r, hx)) != H263MI_OK) break;
                     if (!hx.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
-                    if ((mrc = mvd_table().decode(r, hy)) != H263MI_OK) break;
+                    if ((mrc = t_mvd.decode(r, hy)) != H263MI_OK) break;
                     if (!hy.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
                     mvd[k] = Mv{hx.v0, hy.v0};
                 }
@@ -781,7 +855,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             if (!intra) {                                                      // state.rs:229-285
                 const bool four = mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q;
                 for (int k = 0; k < (four ? 4 : 1); k++) {
-                    const Mv pred = predict_candidate(predictor_vectors, motion_vectors, mb_per_line, k);
+                    const Mv pred = predict_candidate(predictor_vectors, motion_vectors, mb_per_line, k, mb_col, mb_line);
                     motion_vectors[k] = Mv{halfpel_decode(running_options, hdr, hdr.width, pred.x, mvd[k].x, true),
                                            halfpel_decode(running_options, hdr, hdr.height, pred.y, mvd[k].y, false)};
                 }
@@ -792,25 +866,30 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             rec.coeff_index = (uint32_t)out.n_coded_blocks;
             const int coded[6] = {(luma >> 3) & 1, (luma >> 2) & 1, (luma >> 1) & 1, luma & 1, cb, cr};
             for (int b = 0; b < 6; b++) {                                      // state.rs:287-381
-                ParsedBlock blk;
-                rc = decode_block(r, sorenson, hdr.version, intra, coded[b] != 0, blk);
+                if (!intra && !coded[b]) continue;   // an inter block without TCOEFs has no bits at all (block.rs:684-687)
+                // run-length expansion + de-zigzag of inverse_rle (rle.rs:117-136) as the events arrive;
+                // dequantisation is left to the GPU.  A run that walks past zigzag 63 voids the block (rle.rs:125-127).
+                const size_t base = out.coeffs.size();
+                if (coded[b] && want_dense) out.coeffs.resize(base + 64, 0);
+                uint32_t ev[64];                         // a block places 64 events at most
+                int16_t *dense = want_dense ? out.coeffs.data() + base : nullptr;
+                size_t zz = intra ? 1 : 0, n_ev = 0;
+                bool overrun = false;
+                uint8_t dc = 0;
+                rc = decode_block_to(r, sorenson, hdr.version, intra, coded[b] != 0, dc, [&](bool, int run, int level) {
+                    if (overrun) return;
+                    zz += (size_t)run;
+                    if (zz >= 64) { overrun = true; return; }
+                    const uint32_t pos = kZigzagRaster[zz++];
+                    if (dense) dense[pos] = (int16_t)level;
+                    ev[n_ev++] = ((uint32_t)(uint16_t)(int16_t)level << 16) | pos;
+                });
                 if (rc != H263MI_OK) return rc;      // `?` in the reference: a block error fails the whole decode
-                if (intra) rec.intradc[b] = blk.intradc;
+                if (intra) rec.intradc[b] = dc;
                 if (!coded[b]) continue;
                 rec.cbp |= (uint8_t)(1u << b);
-                const size_t base = out.coeffs.size();
-                if (want_dense) out.coeffs.resize(base + 64, 0);
-                // run-length expansion + de-zigzag of inverse_rle (rle.rs:117-136); dequantisation is left
-                // to the GPU.  A run that walks past zigzag 63 voids the block (rle.rs:125-127).
-                size_t zz = intra ? 1 : 0;
-                for (int t = 0; t < blk.n_tcoef; t++) {
-                    zz += blk.tcoef[t].run;
-                    if (zz >= 64) { rec.kill |= (uint8_t)(1u << b); break; }
-                    const uint32_t pos = kZigzagRaster[zz];
-                    if (want_dense) out.coeffs[base + pos] = blk.tcoef[t].level;
-                    out.events.push_back(((uint32_t)(uint16_t)blk.tcoef[t].level << 16) | pos);
-                    zz++;
-                }
+                if (overrun) rec.kill |= (uint8_t)(1u << b);
+                out.events.insert(out.events.end(), ev, ev + n_ev);
                 out.n_coded_blocks++;
                 out.block_first_event.push_back((uint32_t)out.events.size());
             }
@@ -825,6 +904,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             rec.mv[k][1] = motion_vectors[k].y;
             predictor_vectors.push_back(motion_vectors[k]);
         }
+        if (++mb_col == mb_per_line) { mb_col = 0; mb_line++; }
         out.mbs.push_back(rec);
     }
     out.bits_consumed = r.position();

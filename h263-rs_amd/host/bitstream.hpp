@@ -38,6 +38,8 @@ public:
     int read_signed_bits(uint32_t n, int32_t &out);
     int skip_bits(uint32_t n);
     int read_u8(uint32_t &out) { return read_bits(8, out); }
+    // the caller has checked remaining() >= n
+    void advance(uint32_t n) { pos_ += n; }
     // recognize_start_code (reader.rs:244-262): *skipped = bits in front of the start code, or -1 for None
     int recognize_start_code(bool in_error, int &skipped) const;
     // read_umv (reader.rs:298-324): unrestricted motion vector component, half-pel units
@@ -64,11 +66,25 @@ public:
     // EOF if the data ends inside a code word
     int decode(BitReader &r, VlcHit &hit) const;
     int max_len() const { return max_len_; }
+    struct Slot { uint8_t len; uint8_t valid; int8_t v0, v1, v2; };
+    // the slot of the code that starts a 32-bit window of the bitstream (the bits beyond the end of the data, if
+    // any, are zeros: the caller compares Slot::len with what remains).  Two levels: the first is indexed by the
+    // leading 8 bits (256 entries, always in L1) and resolves every code word of up to 8 bits -- the frequent ones;
+    // longer code words continue in a small per-prefix table indexed by the remaining max_len - 8 bits.  (One flat
+    // table of 2^13 entries for TCOEF was 40 KB with accesses spread all over it.)
+    const Slot &lookup32(uint32_t window) const
+    {
+        const First &f = first_[window >> (32 - first_bits_)];
+        if (f.direct) return f.slot;
+        return second_[f.sub + ((window >> (32 - max_len_)) & sub_mask_)];
+    }
 
 private:
-    struct Slot { uint8_t len; uint8_t valid; int8_t v0, v1, v2; };     // 5 bytes: the 13-bit TCOEF table stays near L1 size
-    std::vector<Slot> lut_;
-    int max_len_;
+    struct First { Slot slot; uint8_t direct; uint16_t sub; };
+    std::vector<First> first_;
+    std::vector<Slot> second_;
+    int max_len_, first_bits_;
+    uint32_t sub_mask_;
 };
 
 const VlcTable &tcoef_table();     // Table 16/H.263: v0 = last, v1 = run, v2 = level; escape: v0 = -1

@@ -250,7 +250,8 @@ H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch
 
 // filter 2 neighbouring columns of the horizontal edge whose A row is `row_a`: one packed quartet pair.
 // Columns outside the picture (the strip's 4-pixel offset, the right picture edge) keep their bytes.
-H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, int gx0, int floor_cols, int w)
+// `edge_tile` (uniform): the tile reaches beyond the left or the right picture edge; only then can a column lie outside.
+H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, int gx0, int floor_cols, int w, bool edge_tile)
 {
     uint32_t r[4];
 #pragma unroll
@@ -260,11 +261,8 @@ H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, 
     uint32_t A = bytes_to_pair(r[0], 0, 1), B = bytes_to_pair(r[1], 0, 1), C = bytes_to_pair(r[2], 0, 1), D = bytes_to_pair(r[3], 0, 1);
     deblock_quartet_pk(A, B, C, D, k);
     uint32_t o[4] = {pair_low_bytes(A), sat_pk_u8_i16(B), sat_pk_u8_i16(C), pair_low_bytes(D)};
-    const uint32_t keep = (gx0 >= 0 && gx0 < w ? 0u : 0x00ffu) | (gx0 + 1 >= 0 && gx0 + 1 < w ? 0u : 0xff00u);
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (__ballot(keep != 0))                                // uniform: only tiles at the left / right picture edge
-#endif
-    {
+    if (edge_tile) {
+        const uint32_t keep = (gx0 >= 0 && gx0 < w ? 0u : 0x00ffu) | (gx0 + 1 >= 0 && gx0 + 1 < w ? 0u : 0xff00u);
 #pragma unroll
         for (int q = 0; q < 4; q++) o[q] = (o[q] & ~keep) | (r[q] & keep);
     }
@@ -277,18 +275,19 @@ H263_DEV void post_phase_hedges(const PostArgs &a, PostStrip &s, int lane, int s
 {
     const int xl = sx * POST_TW - POST_OX;
     const int strength = (int)a.strength;
+    const bool edge_tile = xl < 0 || xl + POST_TW > (int)a.L.width;     // (the chroma strip reaches as far, in its own units)
     {
         // luma: the edge's C row is picture row 8*sy = strip row 4; every lane takes 2 columns
         const int gy = sy * POST_SH, w = (int)a.L.width, h = (int)a.L.height;
         if (gy >= 8 && gy <= h - 2)                                      // edge_y <= height - 2 (deblock.rs:140)
-            hfilter2(s.y, POST_TW, 2, lane * 2, strength, xl + lane * 2, (w / 8) * 8, w);
+            hfilter2(s.y, POST_TW, 2, lane * 2, strength, xl + lane * 2, (w / 8) * 8, w, edge_tile);
     }
     if (!a.luma_only && (sy & 1) == 0) {
         // chroma strip rows [4*sy-2, 4*sy+2) hold an edge only when 4*sy is a multiple of 8
         const int gy = sy * POST_CSH, w = (int)a.L.cwidth, h = (int)a.L.cheight;
         const int plane = lane >> 5, col = (lane & 31) * 2;
         if (gy >= 8 && gy <= h - 2)
-            hfilter2(s.c[plane], POST_CW, 0, col, strength, xl / 2 + col, (w / 8) * 8, w);
+            hfilter2(s.c[plane], POST_CW, 0, col, strength, xl / 2 + col, (w / 8) * 8, w, edge_tile);
     }
 }
 
@@ -355,6 +354,20 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
     }
 }
 
+// 16 bytes to an address that is a multiple of 4 (global_store_dwordx4 asks for no more)
+H263_DEV void store16_align4(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+    const u32x4 v = {a, b, c, d};
+    *reinterpret_cast<u32x4_a4 *>(dst) = v;
+#else
+    const uint32_t v[4] = {a, b, c, d};
+    memcpy(dst, v, 16);
+#endif
+}
+
 // ---- phase 3: BT.601 -> RGBA, optional filtered planes -------------------------------------
 // bt601.rs:25-58 regrouped so that everything that depends only on the chroma sample is computed
 // once per 2x2 quad:  R = (Y*76309 + [Cr*104597 + K]) >> 16, etc., K = 32768 - 16*76309 - 128*coef.
@@ -398,8 +411,13 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
     const int w = (int)a.L.width, h = (int)a.L.height, cw = (int)a.L.cwidth, ch = (int)a.L.cheight;
 
     if (a.rgba) {
+        // uniform 64-bit base of the picture + 32-bit lane offsets (w * h * 4 < 2^32: layout_fits)
         uint8_t *rgba = a.rgba + (size_t)pic * w * h * 4;
         const int g = lane & 31, gx = xl + 4 * g;
+        // the lane's four pixels: all inside the picture (the only case away from the left / right picture edge),
+        // or some of them (a picture whose width is not a multiple of 4), or none
+        const bool col_full = gx >= 0 && gx + 4 <= w, col_some = gx >= 0 && gx < w;
+        const uint32_t row_bytes = (uint32_t)w * 4u;
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             // a lane converts a 4x2 block: two rows that share one chroma row (nearest-neighbour
@@ -409,25 +427,34 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
             const uint32_t crv = *reinterpret_cast<const uint16_t *>(&s.c[1][q * POST_CW + 2 * g]);
             const ChromaTerms t0 = bt601_chroma_terms(cbv & 0xff, crv & 0xff);
             const ChromaTerms t1 = bt601_chroma_terms(cbv >> 8, crv >> 8);
+            const int gy0 = yl + 2 * q;
+            // byte offset of pixel (gx, gy0), modulo 2^32: gy0 may be -1 with row gy0 + 1 inside the picture
+            const uint32_t off0 = ((uint32_t)gy0 * (uint32_t)w + (uint32_t)gx) * 4u;
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
-                const int row = 2 * q + rr, gy = yl + row;
-                if (gy < 0 || gy >= h || gx < 0 || gx >= w) continue;
+                const int row = 2 * q + rr, gy = gy0 + rr;
+                if ((uint32_t)gy >= (uint32_t)h || !col_some) continue;                    // row or lane outside the picture
                 const uint32_t yv = *reinterpret_cast<const uint32_t *>(&s.y[row * POST_TW + 4 * g]);
                 uint32_t px[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int gray = (int)((yv >> (8 * k)) & 0xff) * 76309;
+                    int gray = (int)((yv >> (8 * k)) & 0xff) * 76309;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // keep the product on its own: one 24-bit multiply + three plain adds issue faster than the three
+                    // multiply-adds the compiler would make of it (profiles/r01_valu_rate.txt)
+                    asm volatile("" : "+v"(gray));
+#endif
                     const ChromaTerms &t = (k < 2) ? t0 : t1;
                     px[k] = bt601_pack(gray + t.r, gray + t.g, gray + t.b);
                 }
-                uint8_t *dst = rgba + ((size_t)gy * w + gx) * 4;
-                if (gx + 4 <= w && (w & 3) == 0) {
+                const uint32_t off = off0 + (rr ? row_bytes : 0u);
+                if (col_full) {
+                    // one 16-byte store; the address is a multiple of 4 (of 16 when the width is a multiple of 4).
                     // (non-temporal stores here were measured: k_recon gains 5 % from finding its reference planes
                     // in the infinity cache, k_post loses 10-25 %)
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+                    store16_align4(rgba + off, px[0], px[1], px[2], px[3]);
                 } else {
-                    for (int k = 0; k < 4 && gx + k < w; k++) memcpy(dst + 4 * k, &px[k], 4);
+                    for (int k = 0; k < 4 && gx + k < w; k++) memcpy(rgba + (off + 4u * (uint32_t)k), &px[k], 4);
                 }
             }
         }

@@ -210,14 +210,23 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
 {
     const uint8_t *frame = a.frames + (size_t)pic * a.L.frame_bytes;
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
+    // Only the first and the last tile of a row reach beyond the allocated row (uniform test): everywhere else the
+    // lane's bytes are contiguous and need no per-dword clamping -- one offset, the rest are immediate offsets.
+    const bool inside = xl >= 0 && xl + POST_TW <= (int)a.L.pitch_y;
     {
         // uniform base + 32-bit per-lane offset: the loads use scalar-base addressing, no 64-bit VALU adds
         const int row = lane >> 3, col = (lane & 7) * 16;
         const uint32_t rowoff = (uint32_t)clampi(yl + row, 0, (int)a.L.rows_y - 1) * a.L.pitch_y;
+        if (inside) {
+            const uint8_t *p = frame + (rowoff + (uint32_t)(xl + col));
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t gx = (uint32_t)clampi(xl + col + 4 * q, 0, (int)a.L.pitch_y - 4);
-            r.y[q] = *reinterpret_cast<const uint32_t *>(frame + (rowoff + gx));
+            for (int q = 0; q < 4; q++) r.y[q] = *reinterpret_cast<const uint32_t *>(p + 4 * q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t gx = (uint32_t)clampi(xl + col + 4 * q, 0, (int)a.L.pitch_y - 4);
+                r.y[q] = *reinterpret_cast<const uint32_t *>(frame + (rowoff + gx));
+            }
         }
     }
     {
@@ -226,10 +235,16 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
         const int cxl = xl / 2, cyl = yl / 2;                 // xl, yl are even (and may be negative)
         const uint32_t rowoff = (a.luma_only ? 0u : (plane ? a.L.off_cr : a.L.off_cb)) +
                                 (uint32_t)clampi(cyl + row, 0, (int)a.L.rows_c - 1) * a.L.pitch_c;
+        if (inside) {
+            const uint8_t *p = frame + (rowoff + (uint32_t)(cxl + col));
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t gx = (uint32_t)clampi(cxl + col + 2 * q, 0, (int)a.L.pitch_c - 2);
-            r.c[q] = *reinterpret_cast<const uint16_t *>(frame + (rowoff + gx));
+            for (int q = 0; q < 4; q++) r.c[q] = *reinterpret_cast<const uint16_t *>(p + 2 * q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t gx = (uint32_t)clampi(cxl + col + 2 * q, 0, (int)a.L.pitch_c - 2);
+                r.c[q] = *reinterpret_cast<const uint16_t *>(frame + (rowoff + gx));
+            }
         }
     }
 }

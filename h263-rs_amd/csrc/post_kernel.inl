@@ -404,13 +404,14 @@ H263_HD ChromaTerms bt601_chroma_terms(int cb, int cr)
 H263_DEV uint32_t bt601_pack(int r, int g, int b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // v_ashr_pk_u8_i32 does shift + saturate + pack for two values; only bits 15:0 of its result are
-    // defined (tools/probes/probe_ashr_pk.hip), so the halves are merged with a byte permute.
-    uint32_t rg, ba;
+    // v_ashr_pk_u8_i32 does shift + saturate + pack for two values into one half of its destination and keeps the
+    // other half: bits 15:0 in the plain form (tools/probes/probe_ashr_pk.hip), bits 31:16 with op_sel:[0,0,0,1]
+    // (tools/probes/probe_ashr_pk_hi.hip, profiles/r02_probe_ashr_pk_hi.txt) -- four bytes in two instructions.
+    uint32_t px;
     const int alpha = 255 << 16;
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(rg) : "v"(r), "v"(g));
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(ba) : "v"(b), "v"(alpha));
-    return __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(px) : "v"(r), "v"(g));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16 op_sel:[0,0,0,1]" : "+v"(px) : "v"(b), "v"(alpha));
+    return px;
 #else
     // clamp(v >> 16, 0, 255) == clamp(v, 0, 0xFFFFFF) >> 16 (the shift is monotone)
     const uint32_t R = (uint32_t)clampi(r, 0, 0xFFFFFF) >> 16;

@@ -6,7 +6,8 @@
 // of the destination register untouched, while hipcc's lowering of `clamp(a>>n,0,255) | clamp(b>>n,0,255)<<8`
 // consumes the register as if those bits were zero.  When source and destination share a VGPR the
 // stale upper half (a >> 16, unclamped) leaks into the result -- the "shift-then-clamp(C)" column.
-// post_kernel.inl therefore clamps BEFORE shifting, which never selects this instruction.
+// post_kernel.inl therefore never leaves the choice to the compiler: bt601_pack issues the instruction itself (inline
+// asm), once per half of the destination (probe_ashr_pk_hi.hip).
 // Build: hipcc --offload-arch=gfx950 -O2 tools/probes/probe_ashr_pk.hip -o probe_ashr_pk
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -23,16 +23,7 @@ const uint8_t kZigzagRaster[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 2
 uint32_t BitReader::peek_padded(uint32_t n) const
 {
     if (!n) return 0u;
-    const size_t byte = pos_ >> 3, nbytes = nbits_ >> 3;
-    uint64_t window;                      // the 8 bytes at the cursor, big endian, zero padded past the end
-    if (byte + 8 <= nbytes) {
-        memcpy(&window, p_ + byte, 8);    // one unaligned load + byte swap
-        window = __builtin_bswap64(window);
-    } else {
-        window = 0;
-        for (size_t k = 0; k < 8; k++) window = (window << 8) | (byte + k < nbytes ? p_[byte + k] : 0);
-    }
-    return (uint32_t)((window << (pos_ & 7)) >> (64 - n));      // n <= 32 and (pos_ & 7) + n <= 39 < 64
+    return (uint32_t)(peek_window() >> (64 - n));               // n <= 32 <= 57
 }
 
 int BitReader::peek_bits(uint32_t n, uint32_t &out) const
@@ -115,6 +106,7 @@ int BitReader::read_umv(int &out)
 // ---------------------------------------------------------------------------------------------------
 VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0), first_bits_(0), sub_mask_(0)
 {
+    constexpr int kFirstBits = 8;
     for (size_t i = 0; i < n; i++) {
         int l = (int)strlen(codes[i].bits);
         if (l > max_len_) max_len_ = l;
@@ -151,7 +143,7 @@ VlcTable::VlcTable(const VlcCode *codes, size_t n) : max_len_(0), first_bits_(0)
     }
     // Two levels out of it: a prefix of first_bits_ bits whose walks all stop within the prefix gets its slot in the
     // first level; the others get a sub-table of the remaining bits.
-    first_bits_ = max_len_ < 8 ? max_len_ : 8;
+    first_bits_ = max_len_ < kFirstBits ? max_len_ : kFirstBits;
     const int rest = max_len_ - first_bits_;
     sub_mask_ = (1u << rest) - 1u;
     first_.resize((size_t)1 << first_bits_);
@@ -216,7 +208,8 @@ H263MI_TABLE(mvd_table, kMvdCodes)
 // block.  On an error the reader is back where the block started (with_transaction, block.rs:682).
 namespace {
 template <class Sink>
-inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, uint8_t &intradc, Sink &&put)
+inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra, bool tcoef_present, uint8_t &intradc, Sink &&put,
+                           bool field_by_field = false)
 {
     const size_t checkpoint = r.position();
     int rc = H263MI_OK;
@@ -228,42 +221,48 @@ inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra,
             intradc = (uint8_t)code;
         }
         const VlcTable &table = tcoef_table();
+        const bool sorenson_v1 = sorenson && version == 1;   // Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL
+        // (the cursor of the fast path lives in a local: the reader object is shared with code the compiler cannot see
+        // through, and a load + store of its position per event was a quarter of the time of a dense picture)
+        size_t pos = r.position();
+        const size_t end32 = r.size_bits() >= 32 ? r.size_bits() - 32 : 0;
+        const bool have32 = r.size_bits() >= 32 && !field_by_field;
         while (tcoef_present) {
-            if (r.remaining() >= 32) {
+            if (have32 && pos <= end32) {
                 // Fast path: the longest TCOEF event -- escape (7) + Sorenson width flag + LAST + RUN (6) + LEVEL (11)
                 // = 26 bits -- lies inside one 32-bit window of data that is all there: one peek, no per-field
                 // end-of-data checks.  Same bits consumed and same errors as the field-by-field path below.
-                const uint32_t w = r.peek_padded(32);
+                const uint32_t w = (uint32_t)(r.window_at(pos) >> 32);
                 const VlcTable::Slot &sl = table.lookup32(w);
-                uint32_t used = sl.len;
-                if (!sl.valid) { r.advance(used); rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
-                bool last;
-                if (sl.v0 >= 0) {
-                    const uint32_t sign = (w >> (31 - used)) & 1u;
-                    r.advance(used + 1);
-                    last = sl.v0 != 0;
-                    put(true, (int)sl.v1, sign ? -(int)sl.v2 : (int)sl.v2);
-                } else {                                 // ESCAPE (block.rs:689-724)
-                    uint32_t width = 8;
-                    if (sorenson && version == 1) {      // Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL
-                        width = ((w >> (31 - used)) & 1u) ? 11 : 7;
-                        used += 1;
-                    }
-                    last = (w >> (31 - used)) & 1u;
-                    used += 1;
-                    const int run = (int)((w >> (26 - used)) & 63u);
-                    used += 6;
-                    const uint32_t raw = (w >> (32 - used - width)) & ((1u << width) - 1u);
-                    used += width;
-                    const int level = (raw >> (width - 1)) ? (int)(raw | (~0u << width)) : (int)raw;   // reader.rs:176-187
-                    r.advance(used);
-                    if (level == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }
-                    put(false, run, level);
-                }
+                const uint32_t len = sl.len;
+                if (!sl.valid) { rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
+                // Both readings of the window are computed and one is selected without a branch (short code + sign
+                // against ESCAPE, block.rs:689-724): which of the two an event is has no pattern a predictor could learn.
+                // (written as mask arithmetic: the compiler turned `?:` on these into branches again)
+                const uint32_t esc = sl.v0 < 0 ? ~0u : 0u;
+                // short code: sign bit behind the code word
+                const uint32_t sign = (w >> (31 - len)) & 1u;
+                const uint32_t short_level = ((uint32_t)sl.v2 ^ (0u - sign)) + sign;             // sign ? -v2 : v2
+                // ESCAPE: [Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL] LAST, RUN (6), LEVEL (two's complement)
+                const uint32_t flag = sorenson_v1 ? 1u : 0u;
+                const uint32_t width = sorenson_v1 ? 7u + 4u * sign : 8u;                         // (the flag sits where a short code has its sign)
+                const uint32_t e0 = len + flag;                         // position of LAST
+                const uint32_t esc_last = (w >> (31 - e0)) & 1u;
+                const uint32_t esc_run = (w >> (25 - e0)) & 63u;
+                const uint32_t raw = (w >> (25 - e0 - width)) & ((1u << width) - 1u);
+                const uint32_t esc_level = (raw ^ (1u << (width - 1))) - (1u << (width - 1));    // reader.rs:176-187
+                const uint32_t used = ((e0 + 7u + width) & esc) | ((len + 1u) & ~esc);
+                const int level = (int)((esc_level & esc) | (short_level & ~esc));
+                const int run = (int)((esc_run & esc) | ((uint32_t)sl.v1 & ~esc));
+                const bool last = ((esc_last & esc) | ((uint32_t)(sl.v0 != 0) & ~esc)) != 0;
+                pos += used;
+                if (level == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }     // only an ESCAPE can say 0
+                put(esc == 0, run, level);
                 tcoef_present = !last;
                 continue;
             }
             // near the end of the data: field by field, every read checked
+            r.rollback(pos);
             VlcHit h;
             if ((rc = table.decode(r, h)) != H263MI_OK) break;
             if (!h.valid) { rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
@@ -291,7 +290,9 @@ inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra,
                 put(true, (int)h.v1, sign ? -(int)h.v2 : (int)h.v2);
             }
             tcoef_present = !last;
+            pos = r.position();
         }
+        if (rc == H263MI_OK) r.rollback(pos);        // hand the cursor back
     } while (0);
     if (rc != H263MI_OK) r.rollback(checkpoint);
     return rc;
@@ -631,24 +632,20 @@ int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserCo
 namespace {
 struct Mv { int16_t x, y; };
 
-// HalfPel::median_of (types.rs:772-800): the reference's comparison chain, which is the median
-int16_t median3(int16_t self, int16_t mhs, int16_t rhs)
+// HalfPel::median_of (types.rs:772-800): the reference's comparison chain returns the median of the three; here as
+// min / max (no data-dependent branches: the vectors of a P picture are as good as random to a branch predictor)
+inline int16_t median3(int16_t a, int16_t b, int16_t c)
 {
-    if (self > mhs) {
-        if (rhs > mhs) return rhs > self ? self : rhs;
-        return mhs;
-    }
-    if (mhs > rhs) return rhs > self ? rhs : self;
-    return mhs;
+    const int16_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const int16_t m = hi < c ? hi : c;
+    return lo > m ? lo : m;
 }
 
-// predict_candidate (mvd_pred.rs:27-67); pv = vectors of the macroblocks decoded so far
+// predict_candidate (mvd_pred.rs:27-67); pv = vectors of the `current_mb` macroblocks decoded so far, 4 each
 // (`col`, `line`: position of the current macroblock, kept by the caller -- two 64-bit divisions per candidate
 // were a third of the time of a P picture)
-Mv predict_candidate(const std::vector<Mv> &pv /* 4 per MB */, const Mv cur[4], size_t mb_per_line, int index, size_t col,
-                     size_t line)
+inline Mv predict_candidate(const Mv *pv, size_t current_mb, const Mv cur[4], size_t mb_per_line, int index, size_t col, size_t line)
 {
-    const size_t current_mb = pv.size() / 4;
     const Mv zero{0, 0};
     Mv mv1;
     if (index == 0 || index == 2) mv1 = col == 0 ? zero : pv[(current_mb - 1) * 4 + (size_t)index + 1];
@@ -725,7 +722,8 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     out.mbs.clear();
     out.coeffs.clear();
     out.block_first_event.clear();
-    out.events.clear();
+    // (out.events keeps its size as the room to write into -- its elements are plain words -- and is cut to the events
+    // of this picture at the end; after an error its contents mean nothing)
     out.n_coded_blocks = 0;
     out.bits_consumed = 0;
     out.next = ParserContext();
@@ -771,12 +769,36 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     const size_t mb_per_line = (hdr.width + 15u) / 16u, mb_height = (hdr.height + 15u) / 16u;   // state.rs:173-174
     const size_t total = mb_per_line * mb_height;
     int in_force_quantizer = hdr.quantizer;
-    std::vector<Mv> predictor_vectors;             // 4 per decoded macroblock
-    predictor_vectors.reserve(total * 4);
+
+    // Output arrays at their largest size for this picture, written in place and cut to what was used at the end (no
+    // per-element push_back; the event array grows by doubling, a macroblock at a time).
+    static_assert(sizeof(Mv) == sizeof(uint32_t), "Mv is stored in ParsedPicture::scratch");
+    out.scratch.resize(total * 4);                   // vectors of the decoded macroblocks, 4 each
+    Mv *const pv = reinterpret_cast<Mv *>(out.scratch.data());
+    out.mbs.assign(total + 1, h263mi_mb_record{});   // + 1: a macroblock too many is noticed after its blocks were read
+    out.block_first_event.resize((total + 1) * 6 + 1);
+    uint32_t *const first_event = out.block_first_event.data();
+    first_event[0] = 0;
+    size_t n_mbs = 0, n_events = 0, n_blocks = 0;
+    const auto finish = [&](int code) {
+        out.mbs.resize(n_mbs);
+        out.block_first_event.resize(n_blocks + 1);
+        out.events.resize(n_events);
+        out.n_coded_blocks = n_blocks;
+        return code;
+    };
 
     size_t mb_col = 0, mb_line = 0;                  // position of the macroblock being decoded
     const VlcTable &t_mcbpc_i = mcbpc_i_table(), &t_mcbpc_p = mcbpc_p_table(), &t_cbpy = cbpy_table(), &t_mvd = mvd_table();
-    out.mbs.reserve(total);
+    const bool is_i = hdr.picture_type == H263MI_PICTURE_I, is_p = hdr.picture_type == H263MI_PICTURE_P;
+    const bool umv_vectors = (running_options & OPT_UNRESTRICTED_MOTION_VECTORS) && hdr.has_plusptype;
+    const bool umv = (running_options & OPT_UNRESTRICTED_MOTION_VECTORS) != 0;
+    // The macroblock header of an I or P picture can be read out of 64-bit windows (COD + MCBPC + CBPY + DQUANT are 22
+    // bits at most, a vector 26) unless it uses Annex D vectors or Annex T.  Anything irregular -- an invalid code, the
+    // end of the data -- is left to the field-by-field path below, which is the definition of the behaviour.
+    const bool window_header = (is_i || is_p) && !umv_vectors && !(running_options & OPT_MODIFIED_QUANTIZATION) && !out.field_by_field;
+    const VlcTable &t_mcbpc = is_i ? t_mcbpc_i : t_mcbpc_p;
+    static const int kDquant[4] = {-1, -2, 1, 2};
     for (;;) {                                       // state.rs:193-417
         const size_t mb_checkpoint = r.position();   // decode_macroblock runs in a transaction (macroblock.rs:454)
         int mrc = H263MI_OK;
@@ -784,49 +806,99 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         int mb_type = 0, cb = 0, cr = 0, luma = 0, dquant = 0;
         bool has_dquant = false;
         Mv mvd[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        do {                                         // decode_macroblock (macroblock.rs:445-549)
-            uint32_t v;
-            uint32_t cod = 0;
-            if (hdr.picture_type != H263MI_PICTURE_I && (mrc = r.read_bits(1, cod)) != H263MI_OK) break;
-            if (cod) { uncoded = true; break; }
-            VlcHit h;
-            if (hdr.picture_type == H263MI_PICTURE_I) mrc = t_mcbpc_i.decode(r, h);
-            else if (hdr.picture_type == H263MI_PICTURE_P) mrc = t_mcbpc_p.decode(r, h);
-            else mrc = H263MI_ERR_UNIMPLEMENTED_DECODING;            // macroblock.rs:461-465
-            if (mrc != H263MI_OK) break;
-            if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_HEADER; break; }
-            if (h.v0 < 0) { stuffing = true; break; }
-            mb_type = h.v0; cb = h.v1; cr = h.v2;
+        bool have_header = false;
+        if (window_header && r.remaining() >= 64) do {
+            const size_t avail = r.remaining();
+            uint64_t w = r.peek_window();
+            uint32_t used = 0, total_used = 0;       // bits taken from this window / from earlier windows
+            const auto top32 = [&]() { return (uint32_t)((w << used) >> 32); };
+            if (is_p) {
+                used = 1;
+                if (w >> 63) { uncoded = true; r.advance(1); have_header = true; break; }
+            }
+            const VlcTable::Slot &m = t_mcbpc.lookup32(top32());
+            if (!m.valid) break;
+            used += m.len;
+            if (m.v0 < 0) { stuffing = true; r.advance(used); have_header = true; break; }
+            mb_type = m.v0; cb = m.v1; cr = m.v2;
             const bool intra = mb_type == H263MI_MB_INTRA || mb_type == H263MI_MB_INTRA_Q;
-            if ((mrc = t_cbpy.decode(r, h)) != H263MI_OK) break;
-            if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS; break; }
-            luma = intra ? h.v0 : (~h.v0 & 0xf);                     // macroblock.rs:479-489
-            if (running_options & OPT_MODIFIED_QUANTIZATION) { mrc = H263MI_ERR_UNIMPLEMENTED_DECODING; break; }   // macroblock.rs:497-498
+            const VlcTable::Slot &c = t_cbpy.lookup32(top32());
+            if (!c.valid) break;
+            used += c.len;
+            luma = intra ? c.v0 : (~c.v0 & 0xf);                         // macroblock.rs:479-489
             if (mb_type == H263MI_MB_INTER_Q || mb_type == H263MI_MB_INTRA_Q || mb_type == H263MI_MB_INTER4V_Q) {
-                if ((mrc = r.read_bits(2, v)) != H263MI_OK) break;   // decode_dquant (macroblock.rs:257-271)
-                static const int kDquant[4] = {-1, -2, 1, 2};
-                dquant = kDquant[v];
+                dquant = kDquant[(w << used) >> 62];                     // decode_dquant (macroblock.rs:257-271)
+                used += 2;
                 has_dquant = true;
             }
+            bool ok = true;
             if (!intra) {
                 const int n_mv = (mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q) ? 4 : 1;
-                for (int k = 0; k < n_mv && mrc == H263MI_OK; k++) {
-                    if ((running_options & OPT_UNRESTRICTED_MOTION_VECTORS) && hdr.has_plusptype) {
-                        int ux, uy;                                  // Annex D vectors (macroblock.rs:424-430)
-                        if ((mrc = r.read_umv(ux)) != H263MI_OK) break;
-                        if ((mrc = r.read_umv(uy)) != H263MI_OK) break;
-                        mvd[k] = Mv{(int16_t)ux, (int16_t)uy};
-                        continue;
+                for (int k = 0; k < n_mv; k++) {
+                    if (used > 57 - 26) {            // not enough of the window left for two more code words
+                        if (total_used + used > avail) { ok = false; break; }
+                        r.advance(used);
+                        total_used += used;
+                        used = 0;
+                        w = r.peek_window();
                     }
-                    VlcHit hx, hy;                                   // decode_motion_vector (macroblock.rs:414-438)
-                    if ((mrc = t_mvd.decode(r, hx)) != H263MI_OK) break;
-                    if (!hx.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
-                    if ((mrc = t_mvd.decode(r, hy)) != H263MI_OK) break;
-                    if (!hy.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
-                    mvd[k] = Mv{hx.v0, hy.v0};
+                    const VlcTable::Slot &sx = t_mvd.lookup32(top32());  // decode_motion_vector (macroblock.rs:414-438)
+                    used += sx.len;
+                    const VlcTable::Slot &sy = t_mvd.lookup32(top32());
+                    used += sy.len;
+                    if (!sx.valid || !sy.valid) { ok = false; break; }
+                    mvd[k] = Mv{sx.v0, sy.v0};
                 }
             }
+            if (!ok || total_used + used > avail) { r.rollback(mb_checkpoint); break; }   // irregular: field by field
+            r.advance(used);
+            have_header = true;
         } while (0);
+        if (!have_header) {
+            stuffing = uncoded = has_dquant = false;
+            do {                                     // decode_macroblock (macroblock.rs:445-549)
+                uint32_t v;
+                uint32_t cod = 0;
+                if (!is_i && (mrc = r.read_bits(1, cod)) != H263MI_OK) break;
+                if (cod) { uncoded = true; break; }
+                VlcHit h;
+                if (is_i) mrc = t_mcbpc_i.decode(r, h);
+                else if (is_p) mrc = t_mcbpc_p.decode(r, h);
+                else mrc = H263MI_ERR_UNIMPLEMENTED_DECODING;            // macroblock.rs:461-465
+                if (mrc != H263MI_OK) break;
+                if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_HEADER; break; }
+                if (h.v0 < 0) { stuffing = true; break; }
+                mb_type = h.v0; cb = h.v1; cr = h.v2;
+                const bool intra = mb_type == H263MI_MB_INTRA || mb_type == H263MI_MB_INTRA_Q;
+                if ((mrc = t_cbpy.decode(r, h)) != H263MI_OK) break;
+                if (!h.valid) { mrc = H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS; break; }
+                luma = intra ? h.v0 : (~h.v0 & 0xf);                     // macroblock.rs:479-489
+                if (running_options & OPT_MODIFIED_QUANTIZATION) { mrc = H263MI_ERR_UNIMPLEMENTED_DECODING; break; }   // macroblock.rs:497-498
+                if (mb_type == H263MI_MB_INTER_Q || mb_type == H263MI_MB_INTRA_Q || mb_type == H263MI_MB_INTER4V_Q) {
+                    if ((mrc = r.read_bits(2, v)) != H263MI_OK) break;   // decode_dquant (macroblock.rs:257-271)
+                    dquant = kDquant[v];
+                    has_dquant = true;
+                }
+                if (!intra) {
+                    const int n_mv = (mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q) ? 4 : 1;
+                    for (int k = 0; k < n_mv && mrc == H263MI_OK; k++) {
+                        if (umv_vectors) {
+                            int ux, uy;                                  // Annex D vectors (macroblock.rs:424-430)
+                            if ((mrc = r.read_umv(ux)) != H263MI_OK) break;
+                            if ((mrc = r.read_umv(uy)) != H263MI_OK) break;
+                            mvd[k] = Mv{(int16_t)ux, (int16_t)uy};
+                            continue;
+                        }
+                        VlcHit hx, hy;                                   // decode_motion_vector (macroblock.rs:414-438)
+                        if ((mrc = t_mvd.decode(r, hx)) != H263MI_OK) break;
+                        if (!hx.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
+                        if ((mrc = t_mvd.decode(r, hy)) != H263MI_OK) break;
+                        if (!hy.valid) { mrc = H263MI_ERR_INVALID_MVD; break; }
+                        mvd[k] = Mv{hx.v0, hy.v0};
+                    }
+                }
+            } while (0);
+        }
         if (mrc != H263MI_OK) {
             r.rollback(mb_checkpoint);
             // state.rs:387-412: in standard H.263 a macroblock header error looks for the next GOB or picture
@@ -834,15 +906,14 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             if (!sorenson && (mrc == H263MI_ERR_INVALID_MACROBLOCK_HEADER || mrc == H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS)) {
                 int grc = H263MI_OK;
                 if (resync_ends_picture(r, grc)) break;
-                return grc;
+                return finish(grc);
             }
             if (mrc == kEof) break;
-            return mrc;
+            return finish(mrc);
         }
         if (stuffing) continue;                      // Macroblock::Stuffing (state.rs:206)
 
-        h263mi_mb_record rec;
-        memset(&rec, 0, sizeof rec);
+        h263mi_mb_record &rec = out.mbs[n_mbs];      // zero-initialised above
         Mv motion_vectors[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         if (uncoded) {
             // Macroblock::Uncoded: an I picture has no COD bit, so this is always a P picture (state.rs:207-216)
@@ -855,60 +926,77 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             if (!intra) {                                                      // state.rs:229-285
                 const bool four = mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q;
                 for (int k = 0; k < (four ? 4 : 1); k++) {
-                    const Mv pred = predict_candidate(predictor_vectors, motion_vectors, mb_per_line, k, mb_col, mb_line);
-                    motion_vectors[k] = Mv{halfpel_decode(running_options, hdr, hdr.width, pred.x, mvd[k].x, true),
-                                           halfpel_decode(running_options, hdr, hdr.height, pred.y, mvd[k].y, false)};
+                    const Mv pred = predict_candidate(pv, n_mbs, motion_vectors, mb_per_line, k, mb_col, mb_line);
+                    if (!umv) {
+                        // halfpel_decode with the standard range: a sum outside [-32, 32) takes the other
+                        // representative of the difference (mvd_pred.rs:70-117, HalfPel::invert types.rs:736-742)
+                        int x = mvd[k].x + pred.x, y = mvd[k].y + pred.y;
+                        if (x < -32) x += 64; else if (x >= 32) x -= 64;
+                        if (y < -32) y += 64; else if (y >= 32) y -= 64;
+                        motion_vectors[k] = Mv{(int16_t)x, (int16_t)y};
+                    } else {
+                        motion_vectors[k] = Mv{halfpel_decode(running_options, hdr, hdr.width, pred.x, mvd[k].x, true),
+                                               halfpel_decode(running_options, hdr, hdr.height, pred.y, mvd[k].y, false)};
+                    }
                 }
                 if (!four) motion_vectors[1] = motion_vectors[2] = motion_vectors[3] = motion_vectors[0];
             }
             rec.mb_type = (uint8_t)mb_type;
             rec.quant = (uint8_t)in_force_quantizer;
-            rec.coeff_index = (uint32_t)out.n_coded_blocks;
-            const int coded[6] = {(luma >> 3) & 1, (luma >> 2) & 1, (luma >> 1) & 1, luma & 1, cb, cr};
-            for (int b = 0; b < 6; b++) {                                      // state.rs:287-381
-                if (!intra && !coded[b]) continue;   // an inter block without TCOEFs has no bits at all (block.rs:684-687)
+            rec.coeff_index = (uint32_t)n_blocks;
+            // room for the events of this macroblock (6 blocks x 64 at most)
+            if (out.events.size() < n_events + 6 * 64) out.events.resize((n_events + 6 * 64) * 2);
+            const uint32_t coded6 = ((uint32_t)luma << 2) | ((uint32_t)cb << 1) | (uint32_t)cr;   // bit 5 - b: block b
+            // state.rs:287-381: the six blocks in order; an inter block without TCOEFs has no bits at all (block.rs:
+            // 684-687), so an inter macroblock only visits its coded blocks (no branch per absent block)
+            for (uint32_t todo = intra ? 0x3fu : coded6; todo;) {
+                const int b = __builtin_clz(todo) - 26;                        // bit 5 - b, highest first
+                todo &= ~(0x20u >> b);
+                const bool coded = (coded6 >> (5 - b)) & 1u;
                 // run-length expansion + de-zigzag of inverse_rle (rle.rs:117-136) as the events arrive;
                 // dequantisation is left to the GPU.  A run that walks past zigzag 63 voids the block (rle.rs:125-127).
-                const size_t base = out.coeffs.size();
-                if (coded[b] && want_dense) out.coeffs.resize(base + 64, 0);
-                uint32_t ev[64];                         // a block places 64 events at most
-                int16_t *dense = want_dense ? out.coeffs.data() + base : nullptr;
+                int16_t *dense = nullptr;
+                if (coded && want_dense) {
+                    const size_t base = out.coeffs.size();
+                    out.coeffs.resize(base + 64, 0);
+                    dense = out.coeffs.data() + base;
+                }
+                uint32_t *const ev = out.events.data() + n_events;     // a block places 64 events at most
                 size_t zz = intra ? 1 : 0, n_ev = 0;
                 bool overrun = false;
                 uint8_t dc = 0;
-                rc = decode_block_to(r, sorenson, hdr.version, intra, coded[b] != 0, dc, [&](bool, int run, int level) {
+                rc = decode_block_to(r, sorenson, hdr.version, intra, coded, dc, [&](bool, int run, int level) {
                     if (overrun) return;
                     zz += (size_t)run;
                     if (zz >= 64) { overrun = true; return; }
                     const uint32_t pos = kZigzagRaster[zz++];
                     if (dense) dense[pos] = (int16_t)level;
                     ev[n_ev++] = ((uint32_t)(uint16_t)(int16_t)level << 16) | pos;
-                });
-                if (rc != H263MI_OK) return rc;      // `?` in the reference: a block error fails the whole decode
+                }, out.field_by_field);
+                if (rc != H263MI_OK) return finish(rc);   // `?` in the reference: a block error fails the whole decode
                 if (intra) rec.intradc[b] = dc;
-                if (!coded[b]) continue;
+                if (!coded) continue;
                 rec.cbp |= (uint8_t)(1u << b);
                 if (overrun) rec.kill |= (uint8_t)(1u << b);
-                out.events.insert(out.events.end(), ev, ev + n_ev);
-                out.n_coded_blocks++;
-                out.block_first_event.push_back((uint32_t)out.events.size());
+                n_events += n_ev;
+                first_event[++n_blocks] = (uint32_t)n_events;
             }
         }
-        if (predictor_vectors.size() / 4 >= total) {
+        if (n_mbs >= total) {
             // more macroblocks than the picture holds: the reference indexes its level arrays out of bounds
             // here (a panic); reported as an invalid bitstream instead
-            return H263MI_ERR_INVALID_BITSTREAM;
+            return finish(H263MI_ERR_INVALID_BITSTREAM);
         }
         for (int k = 0; k < 4; k++) {
             rec.mv[k][0] = motion_vectors[k].x;
             rec.mv[k][1] = motion_vectors[k].y;
-            predictor_vectors.push_back(motion_vectors[k]);
+            pv[n_mbs * 4 + (size_t)k] = motion_vectors[k];
         }
+        n_mbs++;
         if (++mb_col == mb_per_line) { mb_col = 0; mb_line++; }
-        out.mbs.push_back(rec);
     }
     out.bits_consumed = r.position();
-    return H263MI_OK;
+    return finish(H263MI_OK);
 }
 
 }  // namespace bits

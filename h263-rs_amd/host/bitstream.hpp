@@ -31,6 +31,24 @@ public:
 
     // up to 32 bits starting at the cursor, zero-padded past the end of the data; does not advance
     uint32_t peek_padded(uint32_t n) const;
+    // the bits at the cursor in the top of a 64-bit word, zero-padded past the end; at least the leading
+    // 57 bits (64 - cursor % 8) belong to the stream
+    uint64_t peek_window() const { return window_at(pos_); }
+    // the same at any bit position (hot loops keep their own cursor in a register and store it back with rollback())
+    size_t size_bits() const { return nbits_; }
+    uint64_t window_at(size_t pos) const
+    {
+        const size_t byte = pos >> 3, nbytes = nbits_ >> 3;
+        uint64_t window;
+        if (byte + 8 <= nbytes) {
+            __builtin_memcpy(&window, p_ + byte, 8);          // one unaligned load + byte swap
+            window = __builtin_bswap64(window);
+        } else {
+            window = 0;
+            for (size_t k = 0; k < 8; k++) window = (window << 8) | (byte + k < nbytes ? p_[byte + k] : 0);
+        }
+        return window << (pos & 7);
+    }
     // peek_bits / read_bits / read_signed_bits (reader.rs:94-213): H263MI_ERR_UNHANDLED_IO_ERROR (EOF)
     // when fewer than n bits remain, cursor unchanged
     int peek_bits(uint32_t n, uint32_t &out) const;
@@ -193,8 +211,13 @@ struct ParsedPicture {
     // the same coefficients as events, level << 16 | raster position, block k = [block_first_event[k], [k+1])
     std::vector<uint32_t> block_first_event, events;
     bool want_dense = true;                // set to false before parsing to skip the dense blocks
+    // Test switch: read every field on its own, with its own end-of-data check -- the transcription of the reference's
+    // parser that defines the behaviour -- instead of the windowed fast paths.  tests/test_parser_paths.py holds the two
+    // against each other on valid, truncated and corrupted streams.
+    bool field_by_field = false;
     size_t n_coded_blocks = 0;
     size_t bits_consumed = 0;
+    std::vector<uint32_t> scratch;         // parser-internal (the vectors of the macroblocks decoded so far)
     ParserContext next;                    // the context once this picture has been decoded successfully
 };
 // Returns H263MI_OK or the error the reference's decode_next_picture would return before touching any

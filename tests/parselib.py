@@ -36,6 +36,7 @@ def lib():
         L.pt_read_umv.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.pt_read_umv.restype = None
         L.pt_context_reset.restype = None
+        L.pt_compare_parser_paths.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -68,6 +69,15 @@ def reader_script(data, ops):
     res = np.zeros((len(o), 2), np.int64)
     lib().pt_reader_script(a.ctypes.data, ln, len(o), o.ctypes.data, res.ctypes.data)
     return [(int(r), int(v)) for r, v in res]
+
+
+def compare_parser_paths(data, options=1):
+    """(difference code, return code): the windowed fast paths of parse_picture against its field-by-field form on the
+    same bytes; difference code 0 = every output agrees."""
+    a, ln = _bytes(data)
+    rc = C.c_int()
+    diff = lib().pt_compare_parser_paths(a.ctypes.data, ln, options, C.byref(rc))
+    return diff, rc.value
 
 
 def context_reset():

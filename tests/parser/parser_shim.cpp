@@ -84,6 +84,29 @@ int pt_parse_picture(const uint8_t *data, size_t len, uint32_t options, h263mi_p
     return rc;
 }
 
+// Both forms of the parser on the same bytes: the windowed fast paths against the field-by-field transcription
+// (ParsedPicture::field_by_field).  Returns 0 when every output agrees -- return code, bits consumed, records, dense
+// coefficients, events, block index, the context for the next picture -- else a positive number naming the first
+// difference.  *rc_out = the (field-by-field) return code.
+int pt_compare_parser_paths(const uint8_t *data, size_t len, uint32_t options, int *rc_out)
+{
+    ParsedPicture a, b;
+    b.field_by_field = true;
+    const int ra = parse_picture(data, len, options, nullptr, a), rb = parse_picture(data, len, options, nullptr, b);
+    *rc_out = rb;
+    if (ra != rb) return 1;
+    if (ra != H263MI_OK) return 0;                       // after an error the outputs mean nothing
+    if (a.bits_consumed != b.bits_consumed) return 2;
+    if (memcmp(&a.desc, &b.desc, sizeof a.desc)) return 3;
+    if (a.mbs.size() != b.mbs.size() || (a.mbs.size() && memcmp(a.mbs.data(), b.mbs.data(), a.mbs.size() * sizeof(h263mi_mb_record)))) return 4;
+    if (a.coeffs != b.coeffs) return 5;
+    if (a.events != b.events) return 6;
+    if (a.block_first_event != b.block_first_event || a.n_coded_blocks != b.n_coded_blocks) return 7;
+    if (a.next.have_last != b.next.have_last || a.next.last_format != b.next.last_format ||
+        a.next.last_header_options != b.next.last_header_options) return 8;
+    return 0;
+}
+
 // picture header only.  out: [rc, is_picture, picture_type, width, height, format_kind, options, has_plusptype,
 // has_opptype, mv_range, quantizer, temporal_reference, n_extra, bits_used]
 int pt_parse_header(const uint8_t *data, size_t len, uint32_t options, int use_context, int32_t *out)

@@ -1,0 +1,77 @@
+"""The windowed fast paths of the host parser (one 64-bit window per macroblock header, one 32-bit window per TCOEF event,
+branch-free short / ESCAPE selection -- h263-rs_amd/host/bitstream.cpp) against its field-by-field form, which is the
+transcription of the reference's parser (parser/macroblock.rs:445-549, parser/block.rs:670-755, state.rs:193-427) and
+the definition of the behaviour: same return code, same bits consumed, same records / coefficients / events, on valid
+streams, on every truncation of a stream and on corrupted streams."""
+import numpy as np
+import pytest
+
+import parselib as pl
+import recgen
+import sorenson_enc as enc
+from test_bitstream_e2e import make_codable
+
+
+def _streams():
+    out = []
+    for w, h, seed in ((176, 144, 1), (100, 60, 2), (48, 32, 3)):
+        mbs, co = recgen.intra_picture(w, h, seed=seed, max_level=120)
+        out.append(("I %dx%d" % (w, h), enc.encode_picture(w, h, 0, 7, make_codable(mbs, 7, seed, 0), co), 1))
+        mbs, co = recgen.inter_picture(w, h, seed=seed + 10, mv_range=32, p_4v=0.3, p_intra=0.15, p_coded=0.4, quant=9,
+                                       max_level=100, sparse_low=False)
+        mbs = make_codable(mbs, 9, seed, 1)
+        out.append(("P %dx%d" % (w, h), enc.encode_picture(w, h, 1, 9, mbs, co), 1))
+        out.append(("P stuffing %dx%d" % (w, h), enc.encode_picture(w, h, 1, 9, mbs, co, stuffing_every=3), 1))
+        first = int(np.flatnonzero(mbs["cbp"] & 1)[0])
+        out.append(("P overflow %dx%d" % (w, h), enc.encode_picture(w, h, 1, 9, mbs, co, overflow_blocks={(first, 0)}), 1))
+    # standard H.263 (no Sorenson escape width flag, resynchronisation after macroblock header errors)
+    mbs, co = recgen.inter_picture(176, 144, seed=31, mv_range=30, p_4v=0.2, p_intra=0.1, p_coded=0.4, quant=8, max_level=100,
+                                   sparse_low=False)
+    out.append(("P standard", enc.encode_picture(176, 144, 1, 8, make_codable(mbs, 8, 5, 1), co, standard={}), 0))
+    return out
+
+
+STREAMS = _streams()
+
+
+@pytest.mark.parametrize("name,data,options", STREAMS, ids=[s[0] for s in STREAMS])
+def test_valid_streams_parse_alike(name, data, options):
+    diff, rc = pl.compare_parser_paths(data, options)
+    assert (diff, rc) == (0, 0)
+
+
+@pytest.mark.parametrize("name,data,options", STREAMS, ids=[s[0] for s in STREAMS])
+def test_every_truncation_parses_alike(name, data, options):
+    """The fast paths read ahead of the field they decode; whatever the data ends in -- a header, a vector, a run of
+    TCOEFs -- the outcome (end of picture or EOF error, and everything parsed up to there) must not depend on it."""
+    # every cut of the last 300 bytes (where the windows reach past the end) and a spread of earlier ones
+    cuts = set(range(max(0, len(data) - 300), len(data) + 1)) | set(range(0, len(data), max(1, len(data) // 200)))
+    seen = set()
+    for c in sorted(cuts):
+        diff, rc = pl.compare_parser_paths(data[:c], options)
+        assert diff == 0, (name, c, diff, rc)
+        seen.add(rc)
+    # both kinds of ending occur: the end of the picture (state.rs:411; at least the uncut stream) and a cut inside a block
+    assert 0 in seen and pl.EOF_ERR in seen
+
+
+@pytest.mark.parametrize("name,data,options", STREAMS, ids=[s[0] for s in STREAMS])
+def test_corrupted_streams_parse_alike(name, data, options):
+    """Random bit flips and byte smashes: invalid codes, vectors out of range, runs past zigzag 63, zero escape levels,
+    early start codes.  Any return code is fine as long as both forms agree on it and on every output."""
+    rng = np.random.default_rng(len(data))
+    seen = set()
+    for trial in range(400):
+        buf = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(4, len(buf)))             # (the first bytes are the start code)
+            if rng.random() < 0.7:
+                buf[pos] ^= 1 << int(rng.integers(0, 8))
+            else:
+                buf[pos] = int(rng.integers(0, 256))
+        if rng.random() < 0.3:
+            buf = buf[:int(rng.integers(8, len(buf)))]
+        diff, rc = pl.compare_parser_paths(bytes(buf), options)
+        assert diff == 0, (name, trial, diff, rc)
+        seen.add(rc)
+    assert len(seen) >= 3                                    # the corruptions did reach several error paths

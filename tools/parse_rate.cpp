@@ -2,11 +2,15 @@
 // read from files.  Build and run (CPU only):
 //   g++ -O3 -std=c++17 -Iinclude -o /tmp/parse_rate tools/parse_rate.cpp h263-rs_amd/host/bitstream.cpp
 //   /tmp/parse_rate picture1.bin [picture2.bin ...]        (Sorenson Spark pictures, e.g. from tests/sorenson_enc.py)
-// Measured here (8-core container, 2.1 GHz Xeon, one thread, best of 60): a 1080p I picture of 39 231 coded blocks
-// (2.3 MB) parses in 14.1 ms (164 MB/s), a 1080p P picture with 25 % coded blocks (150 KB) in 1.77 ms (85 MB/s).
-// Round 1: 39.3 ms and 3.45 ms -- the difference is one 32-bit window per TCOEF event (code, sign / escape fields
-// all out of one peek), a two-level VLC table, no division in the vector prediction, parse buffers that keep
-// their capacity from picture to picture.
+// Measured here (8-core container, 2.1 GHz Xeon, one thread, best of 60; the machine is shared, repeat the run and keep
+// the minimum): a 1080p I picture of 39 231 coded blocks / 788 k events (2.3 MB) parses in 10.7 ms (13.6 ns per event),
+// a 1080p P picture with 25 % coded blocks (150 KB, 45 k events) in 1.07 ms.
+// Round 1: 39.3 ms and 3.45 ms.  Round 2, first pass (14.1 / 1.77 ms): one 32-bit window per TCOEF event, a two-level
+// VLC table, no division in the vector prediction, parse buffers that keep their capacity from picture to picture.
+// Second pass (10.7 / 1.07 ms): short code or ESCAPE selected by mask arithmetic instead of a branch (the largest
+// single step: on these streams the kind of an event is random, every other one cost a misprediction), the macroblock
+// header out of one 64-bit window, branch-free median, only the coded blocks of an inter macroblock visited, outputs
+// written in place.  tests/test_parser_paths.py holds the fast paths against the field-by-field form.
 #include <chrono>
 #include <cstdio>
 #include <vector>
@@ -35,7 +39,7 @@ int main(int argc, char **argv)
             if (one < dt) dt = one;
         }
         (void)sum;
-        printf("%s: %zu bytes, %zu MBs, %zu blocks: %.3f ms per parse (best of 60) = %.0f pictures/s per core, %.1f MB/s\n", argv[a], d.size(), p.mbs.size(), p.coeffs.size() / 64, dt * 1e3, 1 / dt, d.size() / 1e6 / dt);
+        printf("%s: %zu bytes, %zu MBs, %zu coded blocks, %zu events: %.3f ms per parse (best of 60) = %.0f pictures/s per core, %.1f MB/s, %.1f ns per event\n", argv[a], d.size(), p.mbs.size(), p.n_coded_blocks, p.events.size(), dt * 1e3, 1 / dt, d.size() / 1e6 / dt, dt * 1e9 / (double)(p.events.size() ? p.events.size() : 1));
         if (!sink) return 1;
     }
 }

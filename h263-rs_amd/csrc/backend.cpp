@@ -603,8 +603,11 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
 // `events`, `n_events`)
 static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
                              const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks,
-                             const uint32_t *const *first_event, const uint32_t *const *events, const uint32_t *n_events)
+                             const uint32_t *const *first_event, const uint32_t *const *events, const uint32_t *n_events,
+                             bool from_parser = false, uint32_t pack_threads = 0)
 {
+    // from_parser: the arrays are what bits::parse_picture just wrote (h263mi_batch_decode_next_pictures) -- valid by
+    // construction, so the per-record checks a caller's arrays get are skipped; pack_threads: the caller's thread budget
     const bool sparse = first_event != nullptr;
     if (!b || !mbs || !n_mbs || !n_coeff_blocks || (!sparse && !coeffs) || (sparse && (!events || !n_events)) ||
         picture_type > H263MI_PICTURE_RESERVED)
@@ -647,7 +650,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     auto pack = [&](uint32_t first, uint32_t last) {
         for (uint32_t i = first; i < last; i++) {
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
-            for (uint32_t k = 0; k < n_mbs[i]; k++) {                   // the same checks as h263mi_submit_picture
+            for (uint32_t k = 0; k < n_mbs[i] && !from_parser; k++) {   // the same checks as h263mi_submit_picture
                 const MbRecord &m = mbs[i][k];
                 // (a record without coded blocks does not use its coeff_index)
                 if (m.mb_type > H263MI_MB_INTER4V_Q || m.quant < 1 || m.quant > 31 || (m.cbp & 0xC0) || (m.kill & 0xC0) ||
@@ -661,16 +664,19 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                 memcpy(g2.h_coeffs + g2.h_base[i] * 64, coeffs[i], (size_t)n_coeff_blocks[i] * 128);
             } else {
                 uint32_t *fo = h_first + g2.h_base[i];
+                bool ascending = true;
                 for (uint32_t k = 0; k < n_coeff_blocks[i]; k++) {
-                    if (first_event[i][k] > first_event[i][k + 1]) offsets_ok.store(false, std::memory_order_relaxed);
+                    ascending = ascending && first_event[i][k] <= first_event[i][k + 1];
                     fo[k] = first_event[i][k] + ev_base[i];
                 }
+                if (!ascending) offsets_ok.store(false, std::memory_order_relaxed);
                 if (n_events[i]) memcpy(h_ev + ev_base[i], events[i], (size_t)n_events[i] * sizeof(uint32_t));
             }
         }
     };
     const size_t bytes = (size_t)b->n * per * sizeof(MbRecord) + (sparse ? event_words * 4 : blocks * 128);
-    const uint32_t n_thr = bytes < (4u << 20) ? 1u : std::min<uint32_t>({8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
+    const uint32_t n_thr = bytes < (4u << 20) ? 1u
+                         : std::min<uint32_t>({pack_threads ? pack_threads : 8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
     if (n_thr <= 1) {
         pack(0, b->n);
     } else {
@@ -774,7 +780,7 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         n_events[i] = (uint32_t)pic.events.size();
     }
     RC_TRY(batch_submit_host(b, picture_type, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
-                             n_events.data()));
+                             n_events.data(), /*from_parser=*/true, n_thr));
     for (uint32_t i = 0; i < n; i++) {
         b->parser_ctx[i] = b->parsed[i].next;
         if (consumed) consumed[i] = b->parsed[i].bits_consumed / 8;          // reader.commit() drains whole bytes

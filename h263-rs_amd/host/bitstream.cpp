@@ -917,8 +917,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         Mv motion_vectors[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         if (uncoded) {
             // Macroblock::Uncoded: an I picture has no COD bit, so this is always a P picture (state.rs:207-216)
+            // (the quantiser of a macroblock without coefficients is never used; a PQUANT of 0, which the header syntax
+            // can express, must not make the record invalid)
             rec.mb_type = H263MI_MB_INTER;
-            rec.quant = (uint8_t)in_force_quantizer;
+            rec.quant = (uint8_t)(in_force_quantizer < 1 ? 1 : in_force_quantizer);
         } else {
             const int q = in_force_quantizer + (has_dquant ? dquant : 0);      // state.rs:226-227
             in_force_quantizer = q < 1 ? 1 : (q > 31 ? 31 : q);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Evidence for profiles/: rocprofv3 kernel stats of the bench workload, then the two PMC passes (FETCH_SIZE,
-# WRITE_SIZE; counters only, separate runs) that feed roofline.traffic, then the default bench line.
+# WRITE_SIZE; counters only, separate runs) that feed roofline.traffic, then the default bench line (which reads them).
 # usage (GPU box, repo root): bash tools/prof_final.sh r02_a      -> gpurun_out/final_r02_a/
 set -u
 TAG=${1:-rXX}
@@ -12,7 +12,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_$C.log
 done
 cd $R
-timeout 1200 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.getcwd())
@@ -42,5 +41,8 @@ json.dump({"tag": tag, "kernel_source_hash": bench.kernel_source_hash(),
            "kernels": traffic}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
 PY
+# the bench line below reports this traffic: same kernel sources, same box (the file is also copied to profiles/ by hand)
+cp $OUT/traffic.json profiles/traffic_latest.json
+timeout 1200 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-900
 ls $OUT/trace/*/ | head

@@ -180,7 +180,7 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
 // neighbouring tiles at any moment: the cache lines that the 4-pixel tile offset makes two tiles
 // share are then fetched once per L2 instead of once per XCD.
 // ---------------------------------------------------------------------------------------
-template <bool FETCH_AHEAD>
+template <bool FETCH_AHEAD, bool STREAM_RGBA>
 __device__ __forceinline__ void post_strip(const PostArgs &a, PostStrip &s, PostFetch &pf, int lane, int sx, int sy, int pic)
 {
     // `ln`: the lane index behind an opaque asm, re-derived per strip so that lane-only expressions (LDS
@@ -203,18 +203,18 @@ __device__ __forceinline__ void post_strip(const PostArgs &a, PostStrip &s, Post
         wave_fence();
         ISA_MARK("vedges_end");
     }
-    post_phase_store(a, s, ln, sx, sy, pic);
+    post_phase_store<STREAM_RGBA>(a, s, ln, sx, sy, pic);
     ISA_MARK("store_end");
 }
 
 // Two strips of a tile.  FETCH_AHEAD: queue the loads of the strips two further down right after each
 // commit, so that they are in flight while this pair is filtered and stored.
-template <bool FETCH_AHEAD>
+template <bool FETCH_AHEAD, bool STREAM_RGBA>
 __device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s, PostFetch &pf0, PostFetch &pf1, int lane,
                                                 int sx, int sy, int pic)
 {
-    post_strip<FETCH_AHEAD>(a, s, pf0, lane, sx, sy, pic);
-    post_strip<FETCH_AHEAD>(a, s, pf1, lane, sx, sy + 1, pic);
+    post_strip<FETCH_AHEAD, STREAM_RGBA>(a, s, pf0, lane, sx, sy, pic);
+    post_strip<FETCH_AHEAD, STREAM_RGBA>(a, s, pf1, lane, sx, sy + 1, pic);
 }
 
 // One wave's share of the post-processing: the 128x32 tile (sx, ty) of picture `pic` = 4 strips.
@@ -222,6 +222,7 @@ __device__ __forceinline__ void post_strip_pair(const PostArgs &a, PostStrip &s,
 // of the one being filtered.  Strips past the bottom of the picture are processed like any other (clamped loads, no
 // rows to store), which keeps the code straight-line and the number of loads fixed, so each wait is an exact
 // s_waitcnt vmcnt(8).
+template <bool STREAM_RGBA>
 __device__ __forceinline__ void post_wave(const PostArgs &a, PostStrip &s, int lane, int sx, int ty, int pic)
 {
     if (ty >= (int)a.tiles_y) return;
@@ -229,8 +230,8 @@ __device__ __forceinline__ void post_wave(const PostArgs &a, PostStrip &s, int l
     PostFetch pf0, pf1;
     post_phase_fetch(a, pf0, lane, sx, sy0, pic);
     post_phase_fetch(a, pf1, lane, sx, sy0 + 1, pic);
-    post_strip_pair<true>(a, s, pf0, pf1, lane, sx, sy0, pic);          // strips 0,1; queues the loads of 2,3
-    post_strip_pair<false>(a, s, pf0, pf1, lane, sx, sy0 + 2, pic);     // strips 2,3
+    post_strip_pair<true, STREAM_RGBA>(a, s, pf0, pf1, lane, sx, sy0, pic);          // strips 0,1; queues the loads of 2,3
+    post_strip_pair<false, STREAM_RGBA>(a, s, pf0, pf1, lane, sx, sy0 + 2, pic);     // strips 2,3
 }
 
 __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     const int pic = (int)blockIdx.y;
     const uint32_t gy = div_tiles_x(wg, a.tiles_x, a.inv_tiles_x);
     const int sx = (int)(wg - gy * a.tiles_x), ty = (int)gy * POST_GROUP + gw;
-    post_wave(a, strips[wave], lane, sx, ty, pic);
+    post_wave<false>(a, strips[wave], lane, sx, ty, pic);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
         p.cbase = 0;
         recon_wave(ra, lds.r, lane, p);
     } else {
-        post_wave(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group, (int)blockIdx.y);
+        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group, (int)blockIdx.y);
     }
 }
 

@@ -369,14 +369,17 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
     }
 }
 
-// 16 bytes to an address that is a multiple of 4 (global_store_dwordx4 asks for no more)
+// 16 bytes to an address that is a multiple of 4 (global_store_dwordx4 asks for no more).  STREAM: a non-temporal
+// store (`nt`) for output that nothing on the device reads again.
+template <bool STREAM>
 H263_DEV void store16_align4(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
     const u32x4 v = {a, b, c, d};
-    *reinterpret_cast<u32x4_a4 *>(dst) = v;
+    if (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a4 *>(dst));
+    else *reinterpret_cast<u32x4_a4 *>(dst) = v;
 #else
     const uint32_t v[4] = {a, b, c, d};
     memcpy(dst, v, 16);
@@ -421,6 +424,10 @@ H263_DEV uint32_t bt601_pack(int r, int g, int b)
 #endif
 }
 
+// STREAM_RGBA: the RGBA stores are non-temporal.  k_frame sets it: the 8.3 MB of RGBA per picture then no longer push
+// the planes that the reconstruction half of the same launch (and the next one) reads out of the L2 / infinity cache --
+// 10 % on a frame index (profiles/README.md).  k_post on its own keeps plain stores: alone, it is 10 % faster with them.
+template <bool STREAM_RGBA>
 H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx, int sy, int pic)
 {
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
@@ -465,10 +472,8 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
                 }
                 const uint32_t off = off0 + (rr ? row_bytes : 0u);
                 if (col_full) {
-                    // one 16-byte store; the address is a multiple of 4 (of 16 when the width is a multiple of 4).
-                    // (non-temporal stores here were measured: k_recon gains 5 % from finding its reference planes
-                    // in the infinity cache, k_post loses 10-25 %)
-                    store16_align4(rgba + off, px[0], px[1], px[2], px[3]);
+                    // one 16-byte store; the address is a multiple of 4 (of 16 when the width is a multiple of 4)
+                    store16_align4<STREAM_RGBA>(rgba + off, px[0], px[1], px[2], px[3]);
                 } else {
                     for (int k = 0; k < 4 && gx + k < w; k++) memcpy(rgba + (off + 4u * (uint32_t)k), &px[k], 4);
                 }

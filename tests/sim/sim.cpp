@@ -134,7 +134,7 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
                     for (int l = 0; l < 64; l++) post_phase_hedges(a, *s, l, sx, sy);
                     for (int l = 0; l < 64; l++) post_phase_vedges(a, *s, l, sx, sy);
                 }
-                for (int l = 0; l < 64; l++) post_phase_store(a, *s, l, sx, sy, pic);
+                for (int l = 0; l < 64; l++) post_phase_store<false>(a, *s, l, sx, sy, pic);
             }
         }
     }

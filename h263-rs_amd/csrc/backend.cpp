@@ -104,6 +104,7 @@ struct h263mi_batch {
     int good_cur = -1;
     bool good_has_ref = false;
     unsigned unsynced_submits = 0;
+    unsigned frame_launches = 0;               // k_frame launches so far: odd ones walk the pictures backwards
     // host-record staging for h263mi_batch_submit_host: two slots (pinned host + device) used alternately, so
     // that packing picture i+1 overlaps the copy and the kernel of picture i
     struct HostStaging {
@@ -278,7 +279,7 @@ struct h263mi_batch {
         if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out], 0));
         if (post) {
             RC_TRY(time_begin(2));
-            HIP_TRY(launch_frame(a, *post, stream));
+            HIP_TRY(launch_frame(a, *post, stream, (frame_launches++ & 1u) != 0));
             RC_TRY(time_end(2));
         } else {
             RC_TRY(time_begin(0));

@@ -32,10 +32,13 @@ struct FrameGeom {
     uint32_t recon_per_group;   // reconstruction sub-tiles (waves) per group: 4 per 8x2-macroblock tile
     uint32_t post_per_group;    // post tiles (waves) per group
     uint32_t inv_per_group;     // ceil(2^32 / (recon_per_group + post_per_group))
+    uint32_t flip;              // walk the pictures of the batch in descending order
 };
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream);
-// k_recon over `rargs` and k_post over `pargs` (same number of pictures, same picture size) as ONE launch
-hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream);
+// k_recon over `rargs` and k_post over `pargs` (same number of pictures, same picture size) as ONE launch.
+// `descending`: walk the pictures last to first.  A caller that alternates the direction from one frame index to the
+// next reads the planes it wrote last -- the ones still in the infinity cache -- first (2 % on a 64-stream batch).
+hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream, bool descending);
 hipError_t launch_post(const PostArgs &args, hipStream_t stream);
 hipError_t launch_synth_headers(const SynthArgs &args, hipStream_t stream);
 hipError_t launch_synth_coeffs(const SynthArgs &args, hipStream_t stream);

@@ -281,18 +281,19 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
     const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group), r = g - group * per_group;
     if (r < fg.recon_per_group) {
         WavePos p;
-        p.pic = (int)blockIdx.y;
+        p.pic = fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
         p.mbx0 = (int)(r >> 2) * TILE_MBX;
         p.mby = (int)group * TILE_MBY + (int)((r >> 1) & 1);
         p.half = (int)(r & 1);
         p.cbase = 0;
         recon_wave(ra, lds.r, lane, p);
     } else {
-        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group, (int)blockIdx.y);
+        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group,
+                        fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y);
     }
 }
 
-hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream)
+hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream, bool descending)
 {
     if (!rargs.n_pictures) return hipSuccess;
     if (rargs.n_pictures != pargs.n_pictures || rargs.n_pictures > 65535) return hipErrorInvalidValue;
@@ -304,6 +305,7 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
     const uint32_t per_group = fg.recon_per_group + fg.post_per_group;
     if ((uint64_t)fg.groups * per_group >= (1u << 24)) return hipErrorInvalidValue;
     fg.inv_per_group = reciprocal_u32(per_group);
+    fg.flip = descending ? 1u : 0u;
     ReconArgs ra = rargs;
     PostArgs pa = pargs;
     ra.inv_tiles_x = reciprocal_u32(rargs.tiles_x);

@@ -499,27 +499,41 @@ def main(argv=None):
         del wl
         dense = Workload(h263mi, n, 1, 0, local_rank, stream, i_kind=h263mi.SYNTH_I_DENSE, p_frames=False)
         fr = dense.frames[0]
-        for it in range(3):
-            batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
-            batch.render_rgba(0, d_rgba.ptr, None)
-        batch.sync()
+
+        def dense_pictures(reps, fused):
+            for it in range(reps):
+                if fused:                              # one launch: I picture f + post-processing of I picture f - 1
+                    batch.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, 0, 0, d_rgba.ptr, None)
+                else:
+                    batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
+                    batch.render_rgba(0, d_rgba.ptr, None)
+            batch.sync()
+
         reps = 200
-        batch.timing_reserve(2 * reps)
-        batch.timing_begin()
-        t1 = time.perf_counter()
-        for it in range(reps):
-            batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
-            batch.render_rgba(0, d_rgba.ptr, None)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        kd = batch.timing_end()
         alg = dense.recon_bytes(0) + dense.post_bytes()
-        extra["config2_dense_iframe"] = {
-            "mp_per_s": round(n * reps * MP_PER_PICTURE / dt, 1),
-            "k_recon_avg_ms": round(kd.recon_ms / max(kd.recon_launches, 1), 4),
-            "k_post_avg_ms": round(kd.post_ms / max(kd.post_launches, 1), 4),
-            "alg_bytes_per_picture": int(alg / n), "pipeline_gbs": round(alg * reps / dt / 1e9, 1),
-            "pipeline_frac": round(alg * reps / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        res = {"alg_bytes_per_picture": int(alg / n)}
+        for fused in ([False, True] if pipeline else [False]):
+            dense_pictures(3, fused)
+            batch.timing_reserve(2 * reps)
+            batch.timing_begin()
+            t1 = time.perf_counter()
+            dense_pictures(reps, fused)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            kd = batch.timing_end()
+            if fused:
+                res.update({"mp_per_s": round(n * reps * MP_PER_PICTURE / dt, 1),
+                            "k_frame_avg_ms": round(kd.frame_ms / max(kd.frame_launches, 1), 4),
+                            "pipeline_gbs": round(alg * reps / dt / 1e9, 1),
+                            "pipeline_frac": round(alg * reps / dt / 1e9 / HBM_PEAK_GBS, 4)})
+            else:
+                res.update({"two_launches_mp_per_s": round(n * reps * MP_PER_PICTURE / dt, 1),
+                            "k_recon_avg_ms": round(kd.recon_ms / max(kd.recon_launches, 1), 4),
+                            "k_post_avg_ms": round(kd.post_ms / max(kd.post_launches, 1), 4)})
+                if not pipeline:
+                    res.update({"mp_per_s": res["two_launches_mp_per_s"], "pipeline_gbs": round(alg * reps / dt / 1e9, 1),
+                                "pipeline_frac": round(alg * reps / dt / 1e9 / HBM_PEAK_GBS, 4)})
+        extra["config2_dense_iframe"] = res
 
     if rank == 0 and world == 1 and not args.no_extra and not args.no_e2e:
         extra["e2e_bitstream"] = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba)

@@ -9,6 +9,16 @@
 
 namespace h263mi {
 
+// Issue priority (s_setprio, 0..3) of the post-processing waves of k_frame; the reconstruction waves stay at 0.  A
+// post wave is a chain of loads and 16-byte stores with little arithmetic in between; let it issue ahead of the
+// reconstruction waves it shares a SIMD with and its memory operations are under way while those fill the vector
+// ALUs.  A/B on two boxes (tools/ab.sh, 2 and 3 rounds): 0 -> 3 is -1.3 % / -1.5 % per frame index, dense I pictures
+// -1 % / +-0; priority 1 -1.1 %.  Raising the reconstruction waves instead (until their loads are in flight, or in
+// the output phase) gains nothing and costs dense I pictures 3 % (profiles/README.md).
+#ifndef H263MI_PRIO_POST
+#define H263MI_PRIO_POST 3
+#endif
+
 // n / d for a wave-uniform n with n * d < 2^32, r = ceil(2^32 / d) made by the launcher (d = 1 has no such r)
 __device__ __forceinline__ uint32_t div_tiles_x(uint32_t n, uint32_t d, uint32_t r) { return d == 1 ? n : __umulhi(n, r); }
 
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
         p.cbase = 0;
         recon_wave(ra, lds.r, lane, p);
     } else {
+        if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
         post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group,
                         fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y);
     }

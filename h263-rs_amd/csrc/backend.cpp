@@ -7,6 +7,13 @@
 #include <new>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -57,6 +64,71 @@ struct DeviceGuard {
     {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
+};
+
+// Host worker threads of a batch (parser tasks, packing into pinned staging): created once and parked between calls --
+// h263mi_batch_decode_next_pictures used to start and join two sets of threads per frame index.  run(k, fn) executes
+// fn(0) .. fn(k - 1), fn(0) on the calling thread, and returns when all are done; calls do not nest or overlap (a batch
+// is driven from one thread at a time).
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned workers)
+    {
+        for (unsigned t = 0; t < workers; t++) threads_.emplace_back([this, t] { loop(t + 1); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    unsigned size() const { return (unsigned)threads_.size() + 1; }       // the caller counts
+    void run(unsigned k, const std::function<void(unsigned)> &fn)
+    {
+        if (k > size()) k = size();
+        if (k <= 1) { fn(0); return; }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn;
+            active_ = k;
+            pending_ = k - 1;
+            generation_++;
+        }
+        wake_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop(unsigned id)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                wake_.wait(l, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                if (id < active_) fn = fn_;
+            }
+            if (!fn) continue;
+            (*fn)(id);
+            std::lock_guard<std::mutex> l(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned active_ = 0, pending_ = 0, generation_ = 0;
+    bool stop_ = false;
 };
 
 uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
@@ -120,6 +192,18 @@ struct h263mi_batch {
     // and the parse results of the current call (kept between calls so that their buffers are reused)
     std::vector<bits::ParserContext> parser_ctx;
     std::vector<bits::ParsedPicture> parsed;
+    std::unique_ptr<WorkerPool> pool;          // host threads of the entry points that take host data
+    WorkerPool &workers(unsigned want)
+    {
+        if (!pool || pool->size() < want) pool.reset(new WorkerPool(want - 1));
+        return *pool;
+    }
+    // H263MI_TRACE_E2E=1: where the host time of h263mi_batch_decode_next_pictures goes (printed when the batch is
+    // destroyed): [0] parser threads, [1] waiting for the staging slot, [2] packing into pinned staging, [3] enqueueing
+    // copies and launches
+    double host_ms[4] = {0, 0, 0, 0};
+    unsigned host_calls = 0;
+    bool trace_host = getenv("H263MI_TRACE_E2E") != nullptr;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -166,6 +250,10 @@ struct h263mi_batch {
     {
         DeviceGuard g(device);
         (void)hipStreamSynchronize(stream);
+        if (trace_host && host_calls)
+            fprintf(stderr, "h263mi batch (%u streams): %u host submits; ms per call: parse %.3f, wait for slot %.3f, pack %.3f, "
+                            "enqueue %.3f\n", n, host_calls, host_ms[0] / host_calls, host_ms[1] / host_calls,
+                    host_ms[2] / host_calls, host_ms[3] / host_calls);
         release_frames();
         if (post_stream) {
             (void)hipStreamSynchronize(post_stream);
@@ -190,6 +278,20 @@ struct h263mi_batch {
         }
     }
 
+    // the fixed-size part of a staging slot: the records of every stream, the per-stream coefficient bases, the event
+    // that says when the slot may be written again
+    int ensure_record_staging(HostStaging &g2)
+    {
+        const size_t total = (size_t)n * L.mbw * L.mbh;
+        // each piece on its own, so that a failed allocation leaves nothing half-initialised for the next call
+        if (!g2.h_mbs) HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
+        if (!g2.d_mbs) HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
+        if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
+        if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
+        if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
+        return H263MI_OK;
+    }
+
     int ensure_host_staging(HostStaging &g2, size_t n_blocks, size_t n_event_words = 0)
     {
         if (n_event_words > g2.cap_events) {
@@ -201,13 +303,7 @@ struct h263mi_batch {
             HIP_TRY(hipMalloc((void **)&g2.d_events, cap * sizeof(uint32_t)));
             g2.cap_events = cap;
         }
-        const size_t total = (size_t)n * L.mbw * L.mbh;
-        // each piece on its own, so that a failed allocation leaves nothing half-initialised for the next call
-        if (!g2.h_mbs) HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
-        if (!g2.d_mbs) HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
-        if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
-        if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
-        if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
+        RC_TRY(ensure_record_staging(g2));
         // with sparse transport the dense blocks exist on the device only (k_expand writes them)
         if (n_blocks > g2.cap_blocks || (!n_event_words && !g2.h_coeffs)) {
             if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
@@ -632,7 +728,9 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];
     const size_t event_words = sparse ? blocks + 1 + n_ev : 0;
     RC_TRY(b->ensure_host_staging(g2, blocks ? blocks : 1, event_words));
+    const auto t_wait0 = std::chrono::steady_clock::now();
     HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
+    const auto t_pack0 = std::chrono::steady_clock::now();
 
     MbRecord pad;                                // state.rs:421-427: Inter, mv (0,0), nothing coded
     memset(&pad, 0, sizeof pad);
@@ -658,7 +756,8 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                     (m.cbp && (uint64_t)m.coeff_index + (uint64_t)__builtin_popcount(m.cbp) > n_coeff_blocks[i]))
                     records_ok.store(false, std::memory_order_relaxed);
             }
-            if (n_mbs[i]) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
+            // (h263mi_batch_decode_next_pictures has its parser write the records straight into this slot)
+            if (n_mbs[i] && mbs[i] != dst) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
             for (size_t k = n_mbs[i]; k < per; k++) dst[k] = pad;
             if (!n_coeff_blocks[i]) continue;
             if (!sparse) {
@@ -681,12 +780,12 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     if (n_thr <= 1) {
         pack(0, b->n);
     } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < n_thr; t++)
-            pool.emplace_back(pack, (uint32_t)((uint64_t)b->n * t / n_thr), (uint32_t)((uint64_t)b->n * (t + 1) / n_thr));
-        for (std::thread &t : pool) t.join();
+        b->workers(n_thr).run(n_thr, [&](unsigned t) {
+            pack((uint32_t)((uint64_t)b->n * t / n_thr), (uint32_t)((uint64_t)b->n * (t + 1) / n_thr));
+        });
     }
     if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
+    const auto t_enq0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, (size_t)b->n * per * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     if (sparse && blocks) {
@@ -706,6 +805,13 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base));
     HIP_TRY(hipEventRecord(g2.done, b->stream));
     b->host_slot++;
+    if (b->trace_host) {
+        const auto t_end = std::chrono::steady_clock::now();
+        b->host_ms[1] += std::chrono::duration<double, std::milli>(t_pack0 - t_wait0).count();
+        b->host_ms[2] += std::chrono::duration<double, std::milli>(t_enq0 - t_pack0).count();
+        b->host_ms[3] += std::chrono::duration<double, std::milli>(t_end - t_enq0).count();
+        b->host_calls++;
+    }
     return H263MI_OK;
 }
 
@@ -734,25 +840,32 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         if (!data[i] && len[i]) return H263MI_ERR_INVALID_ARGUMENT;
     if (b->parser_ctx.size() != n) b->parser_ctx.assign(n, bits::ParserContext());
     if (b->parsed.size() != n) b->parsed.resize(n);
+    // The records are parsed straight into the pinned staging slot this call will copy from (stream i at i * mbs per
+    // picture): no second pass over them.  The slot was last read by the copy of two calls ago.
+    DeviceGuard g(b->device);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];
+    RC_TRY(b->ensure_record_staging(g2));
+    HIP_TRY(hipEventSynchronize(g2.done));
+    const size_t per = (size_t)b->L.mbw * b->L.mbh;
     // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
     std::vector<int> rcs(n, H263MI_OK);
     std::atomic<uint32_t> next{0};
-    auto work = [&]() {
+    auto work = [&](unsigned) {
         for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
             bits::ParsedPicture &pic = b->parsed[i];
             pic.want_dense = false;                              // the coefficients travel as events
+            pic.mbs_ext = g2.h_mbs + (size_t)i * per;
+            pic.mbs_ext_cap = per;
             rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
         }
     };
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
     const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : hw, n, 256u}));
-    if (n_thr == 1) {
-        work();
-    } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < n_thr; t++) pool.emplace_back(work);
-        for (std::thread &t : pool) t.join();
-    }
+    const auto t_parse0 = std::chrono::steady_clock::now();
+    if (n_thr == 1) work(0);
+    else b->workers(n_thr).run(n_thr, work);
+    if (b->trace_host) b->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
     // Any stream's error fails the call before anything is queued: the batch -- frames, reference bookkeeping and
     // what it remembers of the picture headers -- is unchanged (state.rs:142).
     uint8_t picture_type = H263MI_PICTURE_I;
@@ -773,8 +886,8 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     std::vector<uint32_t> n_mbs(n), n_blocks(n), n_events(n);
     for (uint32_t i = 0; i < n; i++) {
         const bits::ParsedPicture &pic = b->parsed[i];
-        mbs[i] = pic.mbs.data();
-        n_mbs[i] = (uint32_t)pic.mbs.size();
+        mbs[i] = pic.records();
+        n_mbs[i] = (uint32_t)pic.n_records();
         first[i] = pic.block_first_event.data();
         events[i] = pic.events.data();
         n_blocks[i] = (uint32_t)pic.n_coded_blocks;

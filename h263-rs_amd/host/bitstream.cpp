@@ -720,6 +720,8 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     // events, and growing that vector from nothing costs as much as parsing a P picture)
     out.desc = h263mi_picture_desc{};
     out.mbs.clear();
+    out.n_mbs_ext = 0;
+    out.mbs_ext_used = false;
     out.coeffs.clear();
     out.block_first_event.clear();
     // (out.events keeps its size as the room to write into -- its elements are plain words -- and is cut to the events
@@ -775,13 +777,20 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     static_assert(sizeof(Mv) == sizeof(uint32_t), "Mv is stored in ParsedPicture::scratch");
     out.scratch.resize(total * 4);                   // vectors of the decoded macroblocks, 4 each
     Mv *const pv = reinterpret_cast<Mv *>(out.scratch.data());
-    out.mbs.assign(total + 1, h263mi_mb_record{});   // + 1: a macroblock too many is noticed after its blocks were read
+    // the records go to the caller's array when it can hold the picture, else into out.mbs
+    const bool ext = out.mbs_ext != nullptr && total <= out.mbs_ext_cap;
+    out.mbs_ext_used = ext;
+    if (ext) memset(out.mbs_ext, 0, total * sizeof(h263mi_mb_record));
+    else out.mbs.assign(total + 1, h263mi_mb_record{});   // + 1: a macroblock too many is noticed after its blocks were read
+    h263mi_mb_record *const recs = ext ? out.mbs_ext : out.mbs.data();
+    h263mi_mb_record one_too_many{};                 // (the caller's array has no room for that one)
     out.block_first_event.resize((total + 1) * 6 + 1);
     uint32_t *const first_event = out.block_first_event.data();
     first_event[0] = 0;
     size_t n_mbs = 0, n_events = 0, n_blocks = 0;
     const auto finish = [&](int code) {
-        out.mbs.resize(n_mbs);
+        if (ext) out.n_mbs_ext = n_mbs < total ? n_mbs : total;
+        else out.mbs.resize(n_mbs);
         out.block_first_event.resize(n_blocks + 1);
         out.events.resize(n_events);
         out.n_coded_blocks = n_blocks;
@@ -913,7 +922,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         }
         if (stuffing) continue;                      // Macroblock::Stuffing (state.rs:206)
 
-        h263mi_mb_record &rec = out.mbs[n_mbs];      // zero-initialised above
+        h263mi_mb_record &rec = (ext && n_mbs >= total) ? one_too_many : recs[n_mbs];      // zero-initialised above
         Mv motion_vectors[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         if (uncoded) {
             // Macroblock::Uncoded: an I picture has no COD bit, so this is always a P picture (state.rs:207-216)

@@ -207,6 +207,14 @@ int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserCo
 struct ParsedPicture {
     h263mi_picture_desc desc{};
     std::vector<h263mi_mb_record> mbs;     // the macroblocks present in the bitstream (<= mbw*mbh)
+    // Optional destination of the records (set before parsing; e.g. a slot of pinned staging memory): when the picture
+    // has at most mbs_ext_cap macroblocks the records are written there instead of into `mbs` (which stays empty), and
+    // n_mbs_ext says how many.  A picture with more macroblocks than that uses `mbs` as usual (mbs_ext_used = false).
+    h263mi_mb_record *mbs_ext = nullptr;
+    size_t mbs_ext_cap = 0, n_mbs_ext = 0;
+    bool mbs_ext_used = false;
+    const h263mi_mb_record *records() const { return mbs_ext_used ? mbs_ext : mbs.data(); }
+    size_t n_records() const { return mbs_ext_used ? n_mbs_ext : mbs.size(); }
     std::vector<int16_t> coeffs;           // 64 per coded block, raster order (only with want_dense)
     // the same coefficients as events, level << 16 | raster position, block k = [block_first_event[k], [k+1])
     std::vector<uint32_t> block_first_event, events;

@@ -37,6 +37,8 @@ def lib():
         L.pt_read_umv.restype = None
         L.pt_context_reset.restype = None
         L.pt_compare_parser_paths.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int)]
+        L.pt_compare_record_destinations.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.POINTER(C.c_int),
+                                                     C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -78,6 +80,15 @@ def compare_parser_paths(data, options=1):
     rc = C.c_int()
     diff = lib().pt_compare_parser_paths(a.ctypes.data, ln, options, C.byref(rc))
     return diff, rc.value
+
+
+def compare_record_destinations(data, cap, options=1):
+    """(difference code, return code, used the caller's array): parse_picture writing its records into a caller's
+    array of `cap` records (ParsedPicture::mbs_ext) against the same parse into its own vector."""
+    a, ln = _bytes(data)
+    rc, used = C.c_int(), C.c_int()
+    diff = lib().pt_compare_record_destinations(a.ctypes.data, ln, options, cap, C.byref(rc), C.byref(used))
+    return diff, rc.value, bool(used.value)
 
 
 def context_reset():

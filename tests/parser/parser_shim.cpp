@@ -107,6 +107,37 @@ int pt_compare_parser_paths(const uint8_t *data, size_t len, uint32_t options, i
     return 0;
 }
 
+// The records written into a caller's array (ParsedPicture::mbs_ext, what h263mi_batch_decode_next_pictures does with
+// its pinned staging) against the records in the vector: 0 when return code, counts, records and everything else
+// agree.  cap: capacity of the caller's array in records; a picture that does not fit must fall back to the vector.
+// *used_ext says which form the parser chose.
+int pt_compare_record_destinations(const uint8_t *data, size_t len, uint32_t options, size_t cap, int *rc_out, int *used_ext)
+{
+    ParsedPicture a, b;
+    std::vector<h263mi_mb_record> ext(cap + 2);
+    // guard records behind the array: the parser must not write past cap
+    memset(ext.data(), 0xA5, ext.size() * sizeof(h263mi_mb_record));
+    b.mbs_ext = ext.data();
+    b.mbs_ext_cap = cap;
+    const int ra = parse_picture(data, len, options, nullptr, a), rb = parse_picture(data, len, options, nullptr, b);
+    *rc_out = ra;
+    *used_ext = b.mbs_ext_used ? 1 : 0;
+    if (ra != rb) return 1;
+    for (size_t k = cap; k < ext.size(); k++) {
+        const uint8_t *g = reinterpret_cast<const uint8_t *>(&ext[k]);
+        for (size_t j = 0; j < sizeof(h263mi_mb_record); j++)
+            if (g[j] != 0xA5) return 9;
+    }
+    if (ra != H263MI_OK) return 0;
+    if (a.bits_consumed != b.bits_consumed) return 2;
+    if (memcmp(&a.desc, &b.desc, sizeof a.desc)) return 3;
+    if (a.mbs.size() != b.n_records() || (a.mbs.size() && memcmp(a.mbs.data(), b.records(), a.mbs.size() * sizeof(h263mi_mb_record)))) return 4;
+    if (b.mbs_ext_used && !b.mbs.empty()) return 5;
+    if (a.events != b.events) return 6;
+    if (a.block_first_event != b.block_first_event || a.n_coded_blocks != b.n_coded_blocks) return 7;
+    return 0;
+}
+
 // picture header only.  out: [rc, is_picture, picture_type, width, height, format_kind, options, has_plusptype,
 // has_opptype, mv_range, quantizer, temporal_reference, n_extra, bits_used]
 int pt_parse_header(const uint8_t *data, size_t len, uint32_t options, int use_context, int32_t *out)

@@ -75,3 +75,43 @@ def test_corrupted_streams_parse_alike(name, data, options):
         assert diff == 0, (name, trial, diff, rc)
         seen.add(rc)
     assert len(seen) >= 3                                    # the corruptions did reach several error paths
+
+
+@pytest.mark.parametrize("name,data,options", STREAMS, ids=[s[0] for s in STREAMS])
+def test_records_written_in_place_equal_the_vector_form(name, data, options):
+    """h263mi_batch_decode_next_pictures has the parser write a stream's records straight into its slot of the pinned
+    staging array (ParsedPicture::mbs_ext): same records, same counts, nothing written behind the slot -- on the whole
+    stream, on truncations, on corrupted data (incl. streams that carry a macroblock too many), and a picture larger
+    than the slot falls back to the parser's own vector."""
+    w, h = [int(v) for v in name.split()[-1].split("x")] if "x" in name else (176, 144)
+    per = ((w + 15) // 16) * ((h + 15) // 16)
+    assert pl.compare_record_destinations(data, per, options) == (0, 0, True)
+    assert pl.compare_record_destinations(data, per + 7, options) == (0, 0, True)
+    assert pl.compare_record_destinations(data, per - 1, options) == (0, 0, False)       # does not fit: vector form
+    rng = np.random.default_rng(len(data) + 1)
+    for c in sorted(set(int(v) for v in rng.integers(8, len(data), 40))):
+        diff, rc, used = pl.compare_record_destinations(data[:c], per, options)
+        assert diff == 0, (name, c, diff, rc)
+    # a second picture appended: the macroblock layer of the first ends at the start code, or -- with the start code
+    # smashed -- reads on into macroblocks the picture has no room for
+    for trial in range(200):
+        buf = bytearray(data + data)
+        for _ in range(int(rng.integers(0, 4))):
+            pos = int(rng.integers(4, len(buf)))
+            buf[pos] = int(rng.integers(0, 256))
+        diff, rc, used = pl.compare_record_destinations(bytes(buf), per, options)
+        assert diff == 0, (name, trial, diff, rc)
+
+
+def test_a_macroblock_too_many_is_noticed_without_writing_behind_the_slot():
+    """the macroblock layer running on into more macroblocks than the picture holds (no start code in between):
+    InvalidBitstream, in both forms, and the guard records behind the caller's array stay untouched"""
+    seen = set()
+    for name, data, options in STREAMS:
+        w, h = [int(v) for v in name.split()[-1].split("x")] if "x" in name else (176, 144)
+        per = ((w + 15) // 16) * ((h + 15) // 16)
+        for skip in (8, 10, 11, 12, 13):
+            diff, rc, used = pl.compare_record_destinations(data + data[skip:], per, options)
+            assert diff == 0 and used, (name, skip, diff, rc)
+            seen.add(rc)
+    assert -12 in seen

@@ -333,7 +333,10 @@ int h263mi_batch_reset(h263mi_batch *b);
 /* as_yuv of stream `stream`'s last picture -> HOST, tightly packed. */
 int h263mi_batch_copy_yuv(h263mi_batch *b, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr);
 
-/* Per-kernel device time between begin/end, measured with hipEvents on the batch stream. */
+/* Per-kernel device time between begin/end, measured with hipEvents on the batch stream.  Back-to-back launches of the
+ * same kernel are bracketed by one pair of events (begin in front of the first, end behind the last) and share the
+ * elapsed time: *_ms / *_launches is the average time from one launch to the next, gaps between launches included --
+ * an upper bound of the kernel's own duration (a pair of events around every launch cost 2 % of the throughput). */
 typedef struct h263mi_kernel_times {
     double   recon_ms;  uint32_t recon_launches;  uint32_t pad0;   /* k_recon on its own */
     double   post_ms;   uint32_t post_launches;   uint32_t pad1;   /* k_post on its own */

@@ -408,3 +408,53 @@ def test_batch_decode_next_pictures_mixed_types_and_lock_step():
         for s in range(n):
             assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# launch timing: back-to-back launches of one kernel share one pair of events (a chain); the counts say how many
+# launches each kernel had, whatever was queued in between
+# ---------------------------------------------------------------------------------------------
+def test_launch_timing_counts_launches_per_kernel():
+    w, h, n = 176, 144, 3
+    mbs_pp = 11 * 9
+    pics = []
+    for f in range(4):
+        kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
+        cap = n * mbs_pp * 6
+        d = (h263mi.DeviceBuffer(n * mbs_pp * 32), h263mi.DeviceBuffer(cap * 128), h263mi.DeviceBuffer(n * 8))
+        h263mi.synth_batch_device(kind, w, h, n, 0, f, d[0].ptr, d[1].ptr, cap, d[2].ptr)
+        pics.append((h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, d))
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+    # frame-pipelined batch: the first picture is a k_recon launch, the next three k_frame launches (one chain), the
+    # post-processing of the last picture a k_post launch at the sync
+    b = h263mi.Batch(n, w, h, pipeline_post=True)
+    b.timing_reserve(16)
+    b.timing_begin()
+    for ptype, d in pics:
+        b.decode(ptype, d[0].ptr, d[1].ptr, d[2].ptr, 0, 5, d_rgba.ptr)
+    b.sync()
+    kt = b.timing_end()
+    assert (kt.recon_launches, kt.frame_launches, kt.post_launches) == (1, 3, 1)
+    assert kt.recon_ms > 0 and kt.frame_ms > 0 and kt.post_ms > 0
+    assert kt.frame_ms < 50 and kt.recon_ms < 50 and kt.post_ms < 50          # milliseconds of three tiny pictures
+    # a copy back to the host between two launches ends the chain: still three launches, in two chains
+    b.timing_begin()
+    b.decode(*([pics[0][0]] + [x.ptr for x in pics[0][1]]), 0, 5, d_rgba.ptr)
+    b.decode(*([pics[1][0]] + [x.ptr for x in pics[1][1]]), 0, 5, d_rgba.ptr)
+    b.copy_yuv(0)
+    b.decode(*([pics[2][0]] + [x.ptr for x in pics[2][1]]), 0, 5, d_rgba.ptr)
+    b.sync()
+    kt = b.timing_end()
+    assert (kt.recon_launches, kt.frame_launches, kt.post_launches) == (1, 2, 1)
+    b.close()
+    # two launches per picture: kernels alternate, every launch is a chain of its own
+    b = h263mi.Batch(n, w, h)
+    b.timing_begin()
+    for ptype, d in pics:
+        b.submit(ptype, d[0].ptr, d[1].ptr, d[2].ptr)
+        b.render_rgba(5, d_rgba.ptr, None)
+    b.sync()
+    kt = b.timing_end()
+    assert (kt.recon_launches, kt.frame_launches, kt.post_launches) == (4, 0, 4)
+    assert kt.recon_ms > 0 and kt.post_ms > 0
+    b.close()

@@ -227,12 +227,31 @@ inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra,
         size_t pos = r.position();
         const size_t end32 = r.size_bits() >= 32 ? r.size_bits() - 32 : 0;
         const bool have32 = r.size_bits() >= 32 && !field_by_field;
+        uint32_t esc_streak = 0;
         while (tcoef_present) {
             if (have32 && pos <= end32) {
                 // Fast path: the longest TCOEF event -- escape (7) + Sorenson width flag + LAST + RUN (6) + LEVEL (11)
                 // = 26 bits -- lies inside one 32-bit window of data that is all there: one peek, no per-field
                 // end-of-data checks.  Same bits consumed and same errors as the field-by-field path below.
                 const uint32_t w = (uint32_t)(r.window_at(pos) >> 32);
+                if (esc_streak >= 2 && (w >> 25) == 3u) {
+                    // A run of ESCAPEs ("0000 011", Table 16/H.263) -- the blocks of an intra picture with large
+                    // levels are little else: the fields sit at fixed places behind the 7-bit code word, no table
+                    // access, a third of the arithmetic of the general form below.  Tried only after two ESCAPEs in a
+                    // row, so that the test is a well-predicted branch where it is taken at all (block.rs:689-724).
+                    // (Reading a second ESCAPE out of the same 64-bit window was tried: the dense I picture gains
+                    // nothing and the general form below comes out of the compiler 50 % slower.)
+                    const uint32_t flagbit = (w >> 24) & 1u;                          // Sorenson v1: selects an 11- or 7-bit LEVEL
+                    const uint32_t width = sorenson_v1 ? 7u + 4u * flagbit : 8u;
+                    const uint32_t e0 = sorenson_v1 ? 8u : 7u;                        // position of LAST
+                    const uint32_t raw = (w >> (25 - e0 - width)) & ((1u << width) - 1u);
+                    const int level = (int)((raw ^ (1u << (width - 1))) - (1u << (width - 1)));
+                    pos += e0 + 7u + width;
+                    if (level == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }
+                    put(false, (int)((w >> (25 - e0)) & 63u), level);
+                    tcoef_present = ((w >> (31 - e0)) & 1u) == 0;
+                    continue;
+                }
                 const VlcTable::Slot &sl = table.lookup32(w);
                 const uint32_t len = sl.len;
                 if (!sl.valid) { rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
@@ -259,6 +278,7 @@ inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra,
                 if (level == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }     // only an ESCAPE can say 0
                 put(esc == 0, run, level);
                 tcoef_present = !last;
+                esc_streak = (esc_streak + 1u) & esc;            // ESCAPEs in a row
                 continue;
             }
             // near the end of the data: field by field, every read checked

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
     const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
     const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
     if (t >= chunk || g >= upp) return;
-    const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group), r = g - group * per_group;
+    const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group);
+    const uint32_t r = g - group * per_group;      // (post tiles in front of the reconstruction sub-tiles: no difference)
     if (r < fg.recon_per_group) {
         WavePos p;
         p.pic = fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;

@@ -196,20 +196,60 @@ H263_DEV uint32_t pack2_u8(int lo, int hi)                     // (lo & 0xff) | 
     return ((uint32_t)lo & 0xffu) | (((uint32_t)hi & 0xffu) << 8);
 #endif
 }
+// ---- interior tiles ---------------------------------------------------------------------------
+// A tile (4 strips) is INTERIOR when every byte its strips load, every sample its filters touch and every pixel it
+// converts lies inside the picture, inside the region where the reference's SIMD lanes do the filtering (floor
+// division: columns < 8*floor(w/8), rows < 8*floor(h/8), for luma and chroma alike), and the call asks for RGBA only.
+// 82 % of the tiles of a 1080p picture are.  For such a tile every bounds test of the phases below is true: the
+// INTERIOR instantiations drop them all -- no clamps, no keep-masks, no predicated stores, constant division biases --
+// and, the point of the exercise, become STRAIGHT-LINE code with a fixed number of vector memory operations per strip
+// (2 loads, 4 stores), so that the compiler can leave exactly the younger loads and stores in flight at each wait
+// (s_waitcnt vmcnt(N)) instead of draining the queue.  Wave-uniform, decided once per wave.
+H263_HD bool post_tile_is_interior(const PostArgs &a, int sx, int ty)
+{
+    const int xl = sx * POST_TW - POST_OX, yl = ty * POST_STRIPS * POST_SH - 4;
+    const int w8 = (int)(a.L.width / 8) * 8, h8 = (int)(a.L.height / 8) * 8;
+    const int cw8 = (int)(a.L.cwidth / 8) * 8, ch8 = (int)(a.L.cheight / 8) * 8;
+    return xl >= 0 && yl >= 0 && xl + POST_TW <= w8 && xl / 2 + POST_CW <= cw8 && yl + POST_STRIPS * POST_SH <= h8 &&
+           yl / 2 + POST_STRIPS * POST_CSH <= ch8 && a.rgba != nullptr && a.planes_out == nullptr && !a.luma_only;
+}
+
 // ---- phase 0: strip -> registers -> LDS -----------------------------------------------------
 struct PostFetch {
     uint32_t y[4];
-    uint32_t c[4];     // one 16-bit pair each, kept unpacked so that nothing touches them before the commit
+    uint32_t c[4];     // edge tiles: one 16-bit pair each, kept unpacked so that nothing touches them before the commit;
+                       // interior tiles: c[0], c[1] = the lane's 8 chroma bytes as loaded
 };
 
 // lane = 16 luma bytes (row = lane/8) and 8 chroma bytes (plane = lane/32, row = (lane/8)%4).
 // Every load is issued unconditionally from a clamped address (bytes outside the picture are never
 // used), so the number of loads per strip is fixed: a wave queues the loads of several strips up
 // front and the wait in front of each strip leaves the later ones in flight (s_waitcnt vmcnt(N)).
+template <bool INTERIOR = false>
 H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx, int sy, int pic)
 {
     const uint8_t *frame = a.frames + (size_t)pic * a.L.frame_bytes;
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
+    if (INTERIOR) {
+        // two loads, nothing else: 16 luma bytes at a 4-byte aligned address, 8 chroma bytes at a 2-byte aligned one
+        const uint8_t *py = frame + ((uint32_t)(yl + (lane >> 3)) * a.L.pitch_y + (uint32_t)(xl + (lane & 7) * 16));
+        const uint8_t *pc = frame + ((lane >> 5 ? a.L.off_cr : a.L.off_cb) +
+                                     (uint32_t)(yl / 2 + ((lane >> 3) & 3)) * a.L.pitch_c + (uint32_t)(xl / 2 + (lane & 7) * 8));
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef u32x2 __attribute__((aligned(2))) u32x2_a2;
+        const u32x4 vy = *reinterpret_cast<const u32x4_a4 *>(py);
+        const u32x2 vc = *reinterpret_cast<const u32x2_a2 *>(pc);
+        r.y[0] = vy.x; r.y[1] = vy.y; r.y[2] = vy.z; r.y[3] = vy.w;
+        r.c[0] = vc.x; r.c[1] = vc.y;
+#else
+        memcpy(r.y, py, 16);
+        memcpy(r.c, pc, 8);
+#endif
+        return;
+    }
     // Only the first and the last tile of a row reach beyond the allocated row (uniform test): everywhere else the
     // lane's bytes are contiguous and need no per-dword clamping -- one offset, the rest are immediate offsets.
     const bool inside = xl >= 0 && xl + POST_TW <= (int)a.L.pitch_y;
@@ -266,11 +306,17 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
     }
 }
 
+template <bool INTERIOR = false>
 H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch &r, int lane)
 {
     {
         const int row = lane >> 3, col = (lane & 7) * 16;
         *reinterpret_cast<uint4 *>(&s.y[row * POST_TW + col]) = make_uint4(r.y[0], r.y[1], r.y[2], r.y[3]);
+    }
+    if (INTERIOR) {
+        const int plane = lane >> 5, row = (lane >> 3) & 3, col = (lane & 7) * 8;
+        *reinterpret_cast<uint64_t *>(&s.c[plane][row * POST_CW + col]) = (uint64_t)r.c[0] | ((uint64_t)r.c[1] << 32);
+        return;
     }
     if (a.luma_only) return;
     {
@@ -283,17 +329,19 @@ H263_DEV void post_phase_commit(const PostArgs &a, PostStrip &s, const PostFetch
 // filter 2 neighbouring columns of the horizontal edge whose A row is `row_a`: one packed quartet pair.
 // Columns outside the picture (the strip's 4-pixel offset, the right picture edge) keep their bytes.
 // `edge_tile` (uniform): the tile reaches beyond the left or the right picture edge; only then can a column lie outside.
+template <bool INTERIOR = false>
 H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, int gx0, int floor_cols, int w, bool edge_tile)
 {
     uint32_t r[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<uint16_t *>(t + (row_a + q) * pitch + col);
     // the two columns are 2k, 2k+1 and floor_cols is a multiple of 8: both lie on the same side of it
-    const QuartetConsts k = quartet_consts(strength, trunc_mask(gx0, floor_cols));
+    // (an interior tile lies left of floor_cols altogether: floor division, constant biases)
+    const QuartetConsts k = quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gx0, floor_cols));
     uint32_t A = bytes_to_pair(r[0], 0, 1), B = bytes_to_pair(r[1], 0, 1), C = bytes_to_pair(r[2], 0, 1), D = bytes_to_pair(r[3], 0, 1);
     deblock_quartet_pk(A, B, C, D, k);
     uint32_t o[4] = {pair_low_bytes(A), sat_pk_u8_i16(B), sat_pk_u8_i16(C), pair_low_bytes(D)};
-    if (edge_tile) {
+    if (!INTERIOR && edge_tile) {
         const uint32_t keep = (gx0 >= 0 && gx0 < w ? 0u : 0x00ffu) | (gx0 + 1 >= 0 && gx0 + 1 < w ? 0u : 0xff00u);
 #pragma unroll
         for (int q = 0; q < 4; q++) o[q] = (o[q] & ~keep) | (r[q] & keep);
@@ -303,10 +351,18 @@ H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, 
 }
 
 // ---- phase 1: the horizontal block edge of the strip (deblock_horiz, deblock.rs:136-181) ------
+template <bool INTERIOR = false>
 H263_DEV void post_phase_hedges(const PostArgs &a, PostStrip &s, int lane, int sx, int sy)
 {
     const int xl = sx * POST_TW - POST_OX;
     const int strength = (int)a.strength;
+    if (INTERIOR) {
+        // every strip of an interior tile holds a luma edge that the reference filters (8 <= 8*sy <= h - 2), every
+        // other one a chroma edge
+        hfilter2<true>(s.y, POST_TW, 2, lane * 2, strength, 0, 0, 0, false);
+        if ((sy & 1) == 0) hfilter2<true>(s.c[lane >> 5], POST_CW, 0, (lane & 31) * 2, strength, 0, 0, 0, false);
+        return;
+    }
     const bool edge_tile = xl < 0 || xl + POST_TW > (int)a.L.width;     // (the chroma strip reaches as far, in its own units)
     {
         // luma: the edge's C row is picture row 8*sy = strip row 4; every lane takes 2 columns
@@ -326,23 +382,25 @@ H263_DEV void post_phase_hedges(const PostArgs &a, PostStrip &s, int lane, int s
 // ---- phase 2: vertical block edges (deblock_vert, deblock.rs:185-299) ----------------------
 // A lane takes the same edge in two vertically adjacent rows 2q, 2q + 1 -- one packed quartet pair.  The strip origin
 // is 4 (mod 8) in y (2 mod 4 for chroma), so a row pair never straddles a multiple of 8: both rows divide alike.
+template <bool INTERIOR = false>
 H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int sx, int sy)
 {
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
     const int strength = (int)a.strength;
+    // (interior tiles: every quartet of the strip lies inside the picture and in the floor-division region)
     {
         // luma: 4 row pairs x 16 edges; the quartet sits in bytes 2..5 of an aligned 8-byte window
         const int row = (lane >> 4) * 2, j = lane & 15;
         const int gy = yl + row, gxa = xl + 8 * j + 2;         // picture column of the "A" sample
         const int w = (int)a.L.width, h = (int)a.L.height;
         // A..D = columns 8k-2 .. 8k+1 with k >= 1 and 8k+1 <= w-1 (chunks of row[2..], deblock.rs:281)
-        if (gy + 1 >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
+        if (INTERIOR || (gy + 1 >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1)) {
             uint64_t *p0 = reinterpret_cast<uint64_t *>(&s.y[row * POST_TW + 8 * j]);
             uint64_t *p1 = reinterpret_cast<uint64_t *>(&s.y[(row + 1) * POST_TW + 8 * j]);
             const uint64_t v0 = *p0, v1 = *p1;
             const uint32_t l0 = (uint32_t)v0, h0 = (uint32_t)(v0 >> 32), l1 = (uint32_t)v1, h1 = (uint32_t)(v1 >> 32);
             uint32_t A = bytes_to_pair2(l0, l1, 2), B = bytes_to_pair2(l0, l1, 3), C = bytes_to_pair2(h0, h1, 0), D = bytes_to_pair2(h0, h1, 1);
-            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
+            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
             // ab = [A'0, B'0, A'1, B'1], cd = [C'0, D'0, C'1, D'1] as bytes
             const uint32_t bs = sat_pk_u8_i16(B), cs = sat_pk_u8_i16(C);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -356,22 +414,22 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
             const uint32_t nh0 = (h0 & 0xffff0000u) | c0 | (d0 << 8), nh1 = (h1 & 0xffff0000u) | c1 | (d1 << 8);
 #endif
             // rows outside the picture (above the first strip, below the last row) keep their bytes
-            if (gy >= 0) *p0 = (uint64_t)nl0 | ((uint64_t)nh0 << 32);
-            if (gy + 1 < h) *p1 = (uint64_t)nl1 | ((uint64_t)nh1 << 32);
+            if (INTERIOR || gy >= 0) *p0 = (uint64_t)nl0 | ((uint64_t)nh0 << 32);
+            if (INTERIOR || gy + 1 < h) *p1 = (uint64_t)nl1 | ((uint64_t)nh1 << 32);
         }
     }
-    if (a.luma_only) return;
+    if (!INTERIOR && a.luma_only) return;
     // chroma: 2 planes x 2 row pairs x 8 edges on lanes 0..31; the quartet is bytes 4..7 of an aligned 8-byte window
     if (lane < 32) {
         const int plane = lane >> 4, row = ((lane >> 3) & 1) * 2, j = lane & 7;
         const int gy = yl / 2 + row, gxa = xl / 2 + 8 * j + 4;
         const int w = (int)a.L.cwidth, h = (int)a.L.cheight;
-        if (gy + 1 >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1) {
+        if (INTERIOR || (gy + 1 >= 0 && gy < h && gxa >= 6 && gxa + 3 <= w - 1)) {
             uint32_t *p0 = reinterpret_cast<uint32_t *>(&s.c[plane][row * POST_CW + 8 * j + 4]);
             uint32_t *p1 = reinterpret_cast<uint32_t *>(&s.c[plane][(row + 1) * POST_CW + 8 * j + 4]);
             const uint32_t v0 = *p0, v1 = *p1;
             uint32_t A = bytes_to_pair2(v0, v1, 0), B = bytes_to_pair2(v0, v1, 1), C = bytes_to_pair2(v0, v1, 2), D = bytes_to_pair2(v0, v1, 3);
-            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
+            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
             const uint32_t bs = sat_pk_u8_i16(B), cs = sat_pk_u8_i16(C);
 #if defined(__HIP_DEVICE_COMPILE__)
             const uint32_t ab = __builtin_amdgcn_perm(bs, A, 0x05020400u), cd = __builtin_amdgcn_perm(D, cs, 0x06010400u);
@@ -380,8 +438,8 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
             const uint32_t n0 = (A & 0xffu) | ((bs & 0xffu) << 8) | ((cs & 0xffu) << 16) | ((D & 0xffu) << 24);
             const uint32_t n1 = ((A >> 16) & 0xffu) | (((bs >> 8) & 0xffu) << 8) | (((cs >> 8) & 0xffu) << 16) | (((D >> 16) & 0xffu) << 24);
 #endif
-            if (gy >= 0) *p0 = n0;
-            if (gy + 1 < h) *p1 = n1;
+            if (INTERIOR || gy >= 0) *p0 = n0;
+            if (INTERIOR || gy + 1 < h) *p1 = n1;
         }
     }
 }
@@ -444,19 +502,19 @@ H263_DEV uint32_t bt601_pack(int r, int g, int b)
 // STREAM_RGBA: the RGBA stores are non-temporal.  k_frame sets it: the 8.3 MB of RGBA per picture then no longer push
 // the planes that the reconstruction half of the same launch (and the next one) reads out of the L2 / infinity cache --
 // 10 % on a frame index (profiles/README.md).  k_post on its own keeps plain stores: alone, it is 10 % faster with them.
-template <bool STREAM_RGBA>
+template <bool STREAM_RGBA, bool INTERIOR = false>
 H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx, int sy, int pic)
 {
     const int xl = sx * POST_TW - POST_OX, yl = sy * POST_SH - 4;
     const int w = (int)a.L.width, h = (int)a.L.height, cw = (int)a.L.cwidth, ch = (int)a.L.cheight;
 
-    if (a.rgba) {
+    if (INTERIOR || a.rgba) {
         // uniform 64-bit base of the picture + 32-bit lane offsets (w * h * 4 < 2^32: layout_fits)
         uint8_t *rgba = a.rgba + (size_t)pic * w * h * 4;
         const int g = lane & 31, gx = xl + 4 * g;
         // the lane's four pixels: all inside the picture (the only case away from the left / right picture edge),
         // or some of them (a picture whose width is not a multiple of 4), or none
-        const bool col_full = gx >= 0 && gx + 4 <= w, col_some = gx >= 0 && gx < w;
+        const bool col_full = INTERIOR || (gx >= 0 && gx + 4 <= w), col_some = INTERIOR || (gx >= 0 && gx < w);
         const uint32_t row_bytes = (uint32_t)w * 4u;
 #pragma unroll
         for (int it = 0; it < 2; it++) {
@@ -473,7 +531,7 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 const int row = 2 * q + rr, gy = gy0 + rr;
-                if ((uint32_t)gy >= (uint32_t)h || !col_some) continue;                    // row or lane outside the picture
+                if (!INTERIOR && ((uint32_t)gy >= (uint32_t)h || !col_some)) continue;     // row or lane outside the picture
                 const uint32_t yv = *reinterpret_cast<const uint32_t *>(&s.y[row * POST_TW + 4 * g]);
                 uint32_t px[4];
 #pragma unroll
@@ -497,7 +555,7 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
             }
         }
     }
-    if (a.planes_out) {
+    if (!INTERIOR && a.planes_out) {
         // tightly packed Y | Cb | Cr, as deblock() returns them (deblock.rs:305-315)
         uint8_t *out = a.planes_out + (size_t)pic * ((size_t)w * h + 2 * (size_t)cw * ch);
         for (int it = 0; it < 4; it++) {

@@ -14,6 +14,25 @@
 
 using namespace h263mi;
 
+template <bool INTERIOR>
+static void sim_post_tile(const PostArgs &a, PostStrip &s, PostFetch (*pf)[64], int sx, int sy0, int pic, uint32_t strength)
+{
+    for (int l = 0; l < 64; l++) post_phase_fetch<INTERIOR>(a, pf[0][l], l, sx, sy0, pic);
+    for (int l = 0; l < 64; l++) post_phase_fetch<INTERIOR>(a, pf[1][l], l, sx, sy0 + 1, pic);
+    for (int k = 0; k < POST_STRIPS; k++) {
+        const int sy = sy0 + k;      // strips past the bottom run too (nothing to store), as on the device
+        memset(&s, 0xA5, sizeof s);
+        for (int l = 0; l < 64; l++) post_phase_commit<INTERIOR>(a, s, pf[k & 1][l], l);
+        if (k + 2 < POST_STRIPS)
+            for (int l = 0; l < 64; l++) post_phase_fetch<INTERIOR>(a, pf[k & 1][l], l, sx, sy + 2, pic);
+        if (strength) {
+            for (int l = 0; l < 64; l++) post_phase_hedges<INTERIOR>(a, s, l, sx, sy);
+            for (int l = 0; l < 64; l++) post_phase_vedges<INTERIOR>(a, s, l, sx, sy);
+        }
+        for (int l = 0; l < 64; l++) post_phase_store<false, INTERIOR>(a, s, l, sx, sy, pic);
+    }
+}
+
 extern "C" {
 
 void sim_layout(uint32_t w, uint32_t h, FrameLayout *out) { *out = make_layout(w, h); }
@@ -122,20 +141,9 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
             const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_GROUP + wave;
             if (ty >= (int)a.tiles_y) continue;
             const int sy0 = ty * POST_STRIPS;
-            for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[0][l], l, sx, sy0, pic);
-            for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[1][l], l, sx, sy0 + 1, pic);
-            for (int k = 0; k < POST_STRIPS; k++) {
-                const int sy = sy0 + k;      // strips past the bottom run too (nothing to store), as on the device
-                memset(s, 0xA5, sizeof *s);
-                for (int l = 0; l < 64; l++) post_phase_commit(a, *s, pf[k & 1][l], l);
-                if (k + 2 < POST_STRIPS)
-                    for (int l = 0; l < 64; l++) post_phase_fetch(a, pf[k & 1][l], l, sx, sy + 2, pic);
-                if (strength) {
-                    for (int l = 0; l < 64; l++) post_phase_hedges(a, *s, l, sx, sy);
-                    for (int l = 0; l < 64; l++) post_phase_vedges(a, *s, l, sx, sy);
-                }
-                for (int l = 0; l < 64; l++) post_phase_store<false>(a, *s, l, sx, sy, pic);
-            }
+            // interior tiles take the instantiations without bounds handling, as on the device (kernels.hip: post_wave)
+            if (post_tile_is_interior(a, sx, ty)) sim_post_tile<true>(a, *s, pf, sx, sy0, pic, strength);
+            else sim_post_tile<false>(a, *s, pf, sx, sy0, pic, strength);
         }
     }
     free(s);

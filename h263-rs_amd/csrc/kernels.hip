@@ -237,6 +237,9 @@ template <bool STREAM_RGBA, bool INTERIOR>
 __device__ __forceinline__ void post_tile(const PostArgs &a, PostStrip &s, int lane, int sx, int ty, int pic)
 {
     const int sy0 = ty * POST_STRIPS;
+    // (The edge-tile instantiation is 5 700 instructions, half of k_frame, for 18 % of the tiles.  As a loop over the
+    // strips with one copy of the strip code k_frame shrinks from 12 100 to 7 700 lines of assembly and runs exactly as
+    // fast, dense I pictures 1 % slower: the instruction cache is not what limits it; the unrolled form stays.)
     PostFetch pf0, pf1;
     post_phase_fetch<INTERIOR>(a, pf0, lane, sx, sy0, pic);
     post_phase_fetch<INTERIOR>(a, pf1, lane, sx, sy0 + 1, pic);

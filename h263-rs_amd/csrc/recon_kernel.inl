@@ -576,6 +576,9 @@ H263_DEV const uint8_t *coeff_row_address(const ReconArgs &a, const WavePos &p, 
 // compensation reads.  A lane whose macroblock takes no prediction behaves like a zero vector (its
 // bytes are dropped in the output phase); lanes whose taps leave the picture are fixed up there too.
 // Every address is a wave-uniform plane base plus a 32-bit lane offset.
+// MC = false: no macroblock of the wave takes a prediction (every wave of an I picture): only the coefficient row is
+// requested -- no reference rows, no addresses for them -- and the output phase starts from zeros.
+template <bool MC = true>
 H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
 {
     const uint8_t *ref = a.ref + (size_t)p.pic * a.L.frame_bytes;
@@ -584,6 +587,10 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
         f.d0 = s.desc[slot][0];                                // (garbage beyond the active tasks: never used)
         f.d1 = s.desc[slot][1];
         f.coef0 = *reinterpret_cast<const uint4 *>(coeff_row_address(a, p, f.d0, slot < recon_n_active(km), r));
+    }
+    if (!MC) {
+        f.flags = f.mvw[0] = f.mvw[1] = 0;
+        return;
     }
     // gather.rs:149: without a reference picture nothing is motion compensated (the error is already
     // in the status word)
@@ -770,6 +777,7 @@ H263_DEV bool recon_block_is_special(const RowIn &ri, int lane, uint64_t rows_an
 }
 
 // ---- phase 5: interpolation + residual + clip + store ------------------------------------
+template <bool MC = true>
 H263_DEV void recon_phase_output(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
 {
     uint8_t *cur = a.cur + (size_t)p.pic * a.L.frame_bytes;
@@ -778,6 +786,18 @@ H263_DEV void recon_phase_output(const ReconArgs &a, ReconWave &s, const WaveFet
     for (int k = 0; k < 3; k++) {
         const SegGeo g = seg_geometry(a, lane, k, p);
         if (!((valid_mask >> g.m) & 1)) continue;
+        if (!MC) {
+            // intra macroblocks start from zeros (gather.rs:136-138): the pixels are the clipped residual, or zero
+            uint32_t lo = 0, hi = 0;
+            if ((act_mask >> g.task) & 1) {
+                const uint4 rv = *reinterpret_cast<const uint4 *>(&s.res[g.resoff]);
+                lo = add_clip_u8x4(0u, rv.x, rv.y);
+                hi = add_clip_u8x4(0u, rv.z, rv.w);
+            }
+            *reinterpret_cast<uint64_t *>(cur + g.plane_off + mad24((uint32_t)g.py, (uint32_t)g.pitch, (uint32_t)g.px)) =
+                (uint64_t)lo | ((uint64_t)hi << 32);
+            continue;
+        }
         SegFetch sf = f.seg[k];
         const uint32_t mvw = f.mvw[k >> 1], flags = f.flags >> (k & 2);
         const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int16_t)(mvw >> 16);

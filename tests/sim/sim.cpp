@@ -87,7 +87,11 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
             }
             for (int l = 0; l < 64; l++) recon_report(a, l, km.inter && !a.has_ref, bad_index);
             for (int l = 0; l < 64; l++) recon_phase_compact(*s, l, ti[l], km.act);
-            for (int l = 0; l < 64; l++) recon_phase_fetch(a, *s, f[l], l, p, km);
+            const bool mc = a.has_ref && km.inter;          // the dispatch of kernels.hip: recon_tail<MC>
+            for (int l = 0; l < 64; l++) {
+                if (mc) recon_phase_fetch<true>(a, *s, f[l], l, p, km);
+                else recon_phase_fetch<false>(a, *s, f[l], l, p, km);
+            }
             const int n_active = recon_n_active(km);
             for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
                 static RowIn ri[64];
@@ -107,7 +111,10 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
                 for (int l = 0; l < 64; l++) any_special = any_special || recon_block_is_special(ri[l], l, rows_any, cols_any);
                 for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special);
             }
-            for (int l = 0; l < 64; l++) recon_phase_output(a, *s, f[l], l, p, km);
+            for (int l = 0; l < 64; l++) {
+                if (mc) recon_phase_output<true>(a, *s, f[l], l, p, km);
+                else recon_phase_output<false>(a, *s, f[l], l, p, km);
+            }
         }
     }
     free(s);

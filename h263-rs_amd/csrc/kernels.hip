@@ -86,13 +86,16 @@ __device__ __forceinline__ void recon_round(const ReconArgs &a, ReconWave &s, co
 
 // fetch -> IDCT rounds -> output of one sub-tile.  MC: some macroblock of the wave takes a prediction.
 template <bool MC>
-__device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, const WaveMasks &km)
+__device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, const WaveMasks &km,
+                                           unsigned long long &t_prev_)
 {
+    (void)t_prev_;                                  // (only the diagnosis build H263MI_PROFILE_PHASES reads the clock)
     int ln = lane;
     WaveFetch f;
     recon_phase_fetch<MC>(a, s, f, ln, p, km);      // every global load of this half is in flight from here
     const int n_active = recon_n_active(km);
     ISA_MARK("fetch_end");
+    PHASE_MARK(2);
     // The first round is peeled off the loop: its coefficient row was requested by the fetch phase, ahead of the
     // reference rows, and straight-line code is what lets the compiler wait for exactly that load
     // (s_waitcnt vmcnt(6)) and leave the six reference loads in flight under the IDCT.  Inside the loop the
@@ -100,6 +103,11 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     if (n_active > 0) recon_round<true>(a, s, f, ln, p, 0, km);
 #pragma unroll 1
     for (int round = 1; round * ROUND_BLOCKS < n_active; round++) recon_round<false>(a, s, f, ln, p, round, km);
+    PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
+#if defined(H263MI_PROFILE_PHASES)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(4);                              // reference rows have arrived
+#endif
     asm volatile("" : "+v"(ln));
     wave_fence();                               // the residual strip is complete
     ISA_MARK("output_begin");
@@ -115,6 +123,8 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
 
 #if defined(H263MI_PROFILE_PHASES)
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#else
+    unsigned long long t_prev_ = 0;
 #endif
     ISA_MARK("prologue_end");
     recon_phase_load(a, s, lane, p);
@@ -142,8 +152,8 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
         // every wave of an I picture -- which issue no reference loads, compute no addresses for them and skip the
         // interpolation (a third of the instructions of a dense intra wave).  Two copies rather than a switch inside one:
         // the wait in front of the first IDCT round must know how many loads were issued behind the coefficient row.
-        if (a.has_ref && km.inter) recon_tail<true>(a, s, ln, p, km);
-        else recon_tail<false>(a, s, ln, p, km);
+        if (a.has_ref && km.inter) recon_tail<true>(a, s, ln, p, km, t_prev_);
+        else recon_tail<false>(a, s, ln, p, km, t_prev_);
         PHASE_MARK(5);
     }
 }

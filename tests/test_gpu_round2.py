@@ -458,3 +458,53 @@ def test_launch_timing_counts_launches_per_kernel():
     assert (kt.recon_launches, kt.frame_launches, kt.post_launches) == (4, 0, 4)
     assert kt.recon_ms > 0 and kt.post_ms > 0
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# k_post: interior tiles (no bounds handling, floor division throughout) against edge tiles (general form).  Sizes at
+# which each term of post_tile_is_interior decides for some tile: widths / heights that are not multiples of 8 (the
+# last 8-aligned column / row starts the truncating region, deblock.rs:99-127 vs 29-42), chroma planes whose own
+# 8-aligned limit ends the interior before the luma one does, pictures one tile wide or high (no interior tile at all).
+# Every strength incl. 0; random planes with low contrast, so that the filters act on most edges.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(524, 300), (516, 292), (1924, 1084), (640, 360), (260, 68), (132, 36), (1028, 44)])
+def test_post_interior_and_edge_tiles_agree_with_the_oracle(w, h):
+    rng = np.random.default_rng(w * 13 + h)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    n = 2
+    b = h263mi.Batch(n, w, h)
+    # a decoded picture whose planes are what we want to filter: intra macroblocks with DC only would be too smooth, so
+    # decode random intra pictures (their planes are arbitrary bytes as far as the post-processing is concerned)
+    refs = []
+    mbs_l, co_l = [], []
+    for s in range(n):
+        mbs, co = recgen.intra_picture(w, h, seed=int(rng.integers(1 << 30)), max_level=6)
+        mbs_l.append(mbs)
+        co_l.append(co)
+        rc, ref = orc.decode_picture(w, h, mbs, co, None)
+        assert rc == 0
+        refs.append(ref)
+    b.submit_host(h263mi.PICTURE_I, mbs_l, co_l)
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+    d_planes = h263mi.DeviceBuffer(n * (w * h + 2 * cw * ch))
+    for strength in (0, 1, 5, 9, 12):
+        want = []
+        for s in range(n):
+            filt = refs[s] if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(refs[s], (w, cw, cw)))
+            want.append((filt, orc.yuv420_to_rgba(*filt, w)))
+        # RGBA only: interior tiles take the instantiations without bounds handling
+        b.render_rgba(strength, d_rgba.ptr, None)
+        b.sync()
+        for s in range(n):
+            got = d_rgba.download(w * h * 4, s * w * h * 4)
+            bad = np.flatnonzero(got != want[s][1])
+            assert bad.size == 0, "RGBA %dx%d strength %d stream %d: %d bytes differ, first at pixel %s" % (
+                w, h, strength, s, bad.size, divmod(int(bad[0]) // 4, w))
+        # RGBA + filtered planes: every tile takes the general form; same pixels
+        b.render_rgba(strength, d_rgba.ptr, d_planes.ptr)
+        b.sync()
+        for s in range(n):
+            assert (d_rgba.download(w * h * 4, s * w * h * 4) == want[s][1]).all(), (strength, s)
+            got = d_planes.download(w * h + 2 * cw * ch, s * (w * h + 2 * cw * ch))
+            assert (got == np.concatenate(want[s][0])).all(), (strength, s)
+    b.close()

@@ -128,6 +128,24 @@ def test_post_rgba(w, h, strength):
     assert (rgba == orc.yuv420_to_rgba(*planes, w)).all()
 
 
+@pytest.mark.parametrize("w,h", [(524, 300), (516, 292), (260, 68), (132, 36), (392, 100)])
+@pytest.mark.parametrize("strength", [0, 3, 11])
+def test_post_rgba_interior_and_edge_tiles(w, h, strength):
+    """sizes at which each term of post_tile_is_interior decides for some tile (widths / heights that are not multiples
+    of 8, chroma limits that end the interior before the luma ones, pictures one tile wide or high); low-contrast planes,
+    so that the filters act on most edges; RGBA only (interior instantiations) and RGBA + planes (general form)"""
+    rng = np.random.default_rng(w * 5 + h + strength)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    planes = tuple(np.clip(rng.normal(128, 7, n), 0, 255).astype(np.uint8) for n in (w * h, cw * ch, cw * ch))
+    want = planes if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(planes, (w, cw, cw)))
+    rgba, _ = simlib.post(w, h, planes, strength, want_planes=False)
+    assert (rgba == orc.yuv420_to_rgba(*want, w)).all()
+    rgba, got = simlib.post(w, h, planes, strength)
+    assert (rgba == orc.yuv420_to_rgba(*want, w)).all()
+    for g, e in zip(got, want):
+        assert (g == e).all()
+
+
 def test_post_rgba_reference_pictures():
     bt = json.load(open(os.path.join(GOLD, "bt601_reference_tests.json")))
     for p in bt["pictures"]:

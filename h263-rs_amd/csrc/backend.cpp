@@ -133,8 +133,13 @@ private:
 
 uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
 uint32_t recon_tiles_y(const FrameLayout &L) { return (L.mbh + TILE_MBY - 1) / TILE_MBY; }
-uint32_t post_tiles_x(const FrameLayout &L) { return (L.width + POST_OX + POST_TW - 1) / POST_TW; }
 uint32_t post_tiles_y(const FrameLayout &L) { return (post_strips_y(L.height) + POST_STRIPS - 1) / POST_STRIPS; }
+// tile geometry of k_post for the layout in a.L (post_kernel.inl: post_tile_columns)
+void set_post_tiles(PostArgs &a)
+{
+    a.tiles_x = post_tile_columns(a.L.width, &a.wrap);
+    a.tiles_y = post_tiles_y(a.L);
+}
 
 }  // namespace
 
@@ -419,8 +424,7 @@ struct h263mi_batch {
         a.planes_out = d_planes;
         a.n_pictures = n;
         a.strength = strength;
-        a.tiles_x = post_tiles_x(L);
-        a.tiles_y = post_tiles_y(L);
+        set_post_tiles(a);
         a.luma_only = 0;
         return a;
     }
@@ -1275,8 +1279,7 @@ int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t streng
     a.planes_out = (uint8_t *)planes.p;
     a.n_pictures = 1;
     a.strength = strength;
-    a.tiles_x = post_tiles_x(L);
-    a.tiles_y = post_tiles_y(L);
+    set_post_tiles(a);
     a.luma_only = 1;
     HIP_TRY(launch_post(a, nullptr));
     HIP_TRY(hipMemcpy(out, planes.p, len, hipMemcpyDeviceToHost));
@@ -1309,8 +1312,7 @@ int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len, const uint8_t *c
     a.planes_out = nullptr;
     a.n_pictures = 1;
     a.strength = 0;
-    a.tiles_x = post_tiles_x(L);
-    a.tiles_y = post_tiles_y(L);
+    set_post_tiles(a);
     a.luma_only = 0;
     HIP_TRY(launch_post(a, nullptr));
     HIP_TRY(hipMemcpy(rgba_out, rgba.p, y_len * 4, hipMemcpyDeviceToHost));

@@ -133,6 +133,8 @@ struct PostArgs {
     uint32_t tiles_x, tiles_y;
     uint32_t luma_only;          // standalone deblock() of a single plane
     uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x) (set by the launcher)
+    uint32_t wrap;               // 1: tile column 0 does not exist, its 4 picture columns ride in the last tile (post_kernel.inl)
+    uint32_t pad;
 };
 
 // ---------------------------------------------------------------------------

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     const int gw = (int)(unit % kUnitsPerGroup) * POST_WAVES + wave;       // tile of the group, 0..3
     const int pic = (int)blockIdx.y;
     const uint32_t gy = div_tiles_x(wg, a.tiles_x, a.inv_tiles_x);
-    const int sx = (int)(wg - gy * a.tiles_x), ty = (int)gy * POST_GROUP + gw;
+    const int sx = (int)(wg - gy * a.tiles_x + a.wrap), ty = (int)gy * POST_GROUP + gw;      // (wrap: the first tile column is 1)
     post_wave<false>(a, strips[wave], lane, sx, ty, pic);
 }
 
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
         recon_wave(ra, lds.r, lane, p);
     } else {
         if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
-        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group), (int)group,
+        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group,
                         fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y);
     }
 }

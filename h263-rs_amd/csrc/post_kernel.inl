@@ -43,6 +43,34 @@ struct PostStrip {
 
 H263_HD uint32_t post_strips_y(uint32_t h) { return (h + 4 + POST_SH - 1) / POST_SH; }
 
+// Tile columns of a picture, and the WRAP.  Tile column sx covers picture columns sx*128 - 124 .. sx*128 + 3, so column 0
+// holds just the 4 leftmost picture columns (and 2 chroma columns) -- a wave for 4 x 32 pixels -- while the last tile
+// usually has columns to spare beyond the right picture edge (4 of them at 1920).  The 4 left columns take part in no
+// vertical-edge quartet (the first one is columns 6..9, deblock.rs:281) and horizontal edges are filtered column by
+// column, so they can sit anywhere: when the last tile has >= 4 spare columns and the width is a multiple of 4, they
+// ride in its strip columns w - xl .. w - xl + 3 (chroma: the 2 columns behind the last chroma column), tile column 0
+// is dropped (a.wrap = 1: the first tile is sx = 1) and a 1080p picture takes 15 instead of 16 waves per 32 rows.
+// In those strip columns the picture column is x - w; the quartet test of the vertical edges sees them as outside.
+H263_HD uint32_t post_tile_columns(uint32_t w, uint32_t *wrap)
+{
+    const uint32_t tiles = (w + POST_OX + POST_TW - 1) / POST_TW;
+    const uint32_t spare = tiles * POST_TW - POST_OX - w;
+    *wrap = (tiles >= 2 && (w % 4) == 0 && spare >= 4) ? 1u : 0u;
+    return tiles - *wrap;
+}
+// picture column of strip column `x` (luma), `cx` (chroma)
+// (exactly the 4 / 2 columns behind the picture edge: whatever else the last tile has to spare stays outside)
+H263_HD int post_wrap_x(const PostArgs &a, int x)
+{
+    const int w = (int)a.L.width;
+    return (a.wrap && x >= w && x < w + 4) ? x - w : x;
+}
+H263_HD int post_wrap_cx(const PostArgs &a, int cx)
+{
+    const int cw = (int)a.L.cwidth;
+    return (a.wrap && cx >= cw && cx < cw + 2) ? cx - cw : cx;
+}
+
 // One A,B,C,D quartet (deblock.rs:29-42 / 99-127).  The reference's SIMD lanes divide with arithmetic shifts
 // (floor), its scalar tails with `/` (truncation toward zero).  Both are one shift once a bias is added to
 // negative numerators: trunc(x / 2^k) = (x + ((x >> 31) & (2^k - 1))) >> k.  `tm` is 0 for the floor semantics
@@ -273,7 +301,8 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t gx = (uint32_t)clampi(xl + col + 4 * q, 0, (int)a.L.pitch_y - 4);
+                // (wrap: the dword behind the last picture column is the dword of picture columns 0..3)
+                const uint32_t gx = (uint32_t)clampi(post_wrap_x(a, xl + col + 4 * q), 0, (int)a.L.pitch_y - 4);
                 r.y[q] = *reinterpret_cast<const uint32_t *>(frame + (rowoff + gx));
             }
         }
@@ -299,7 +328,7 @@ H263_DEV void post_phase_fetch(const PostArgs &a, PostFetch &r, int lane, int sx
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t gx = (uint32_t)clampi(cxl + col + 2 * q, 0, (int)a.L.pitch_c - 2);
+                const uint32_t gx = (uint32_t)clampi(post_wrap_cx(a, cxl + col + 2 * q), 0, (int)a.L.pitch_c - 2);
                 r.c[q] = *reinterpret_cast<const uint16_t *>(frame + (rowoff + gx));
             }
         }
@@ -368,14 +397,14 @@ H263_DEV void post_phase_hedges(const PostArgs &a, PostStrip &s, int lane, int s
         // luma: the edge's C row is picture row 8*sy = strip row 4; every lane takes 2 columns
         const int gy = sy * POST_SH, w = (int)a.L.width, h = (int)a.L.height;
         if (gy >= 8 && gy <= h - 2)                                      // edge_y <= height - 2 (deblock.rs:140)
-            hfilter2(s.y, POST_TW, 2, lane * 2, strength, xl + lane * 2, (w / 8) * 8, w, edge_tile);
+            hfilter2(s.y, POST_TW, 2, lane * 2, strength, post_wrap_x(a, xl + lane * 2), (w / 8) * 8, w, edge_tile);
     }
     if (!a.luma_only && (sy & 1) == 0) {
         // chroma strip rows [4*sy-2, 4*sy+2) hold an edge only when 4*sy is a multiple of 8
         const int gy = sy * POST_CSH, w = (int)a.L.cwidth, h = (int)a.L.cheight;
         const int plane = lane >> 5, col = (lane & 31) * 2;
         if (gy >= 8 && gy <= h - 2)
-            hfilter2(s.c[plane], POST_CW, 0, col, strength, xl / 2 + col, (w / 8) * 8, w, edge_tile);
+            hfilter2(s.c[plane], POST_CW, 0, col, strength, post_wrap_cx(a, xl / 2 + col), (w / 8) * 8, w, edge_tile);
     }
 }
 
@@ -511,7 +540,7 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
     if (INTERIOR || a.rgba) {
         // uniform 64-bit base of the picture + 32-bit lane offsets (w * h * 4 < 2^32: layout_fits)
         uint8_t *rgba = a.rgba + (size_t)pic * w * h * 4;
-        const int g = lane & 31, gx = xl + 4 * g;
+        const int g = lane & 31, gx = INTERIOR ? xl + 4 * g : post_wrap_x(a, xl + 4 * g);
         // the lane's four pixels: all inside the picture (the only case away from the left / right picture edge),
         // or some of them (a picture whose width is not a multiple of 4), or none
         const bool col_full = INTERIOR || (gx >= 0 && gx + 4 <= w), col_some = INTERIOR || (gx >= 0 && gx < w);
@@ -560,7 +589,7 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
         uint8_t *out = a.planes_out + (size_t)pic * ((size_t)w * h + 2 * (size_t)cw * ch);
         for (int it = 0; it < 4; it++) {
             const int item = it * 64 + lane, row = item >> 5, g = item & 31;
-            const int gy = yl + row, gx = xl + 4 * g;
+            const int gy = yl + row, gx = post_wrap_x(a, xl + 4 * g);
             if (gy < 0 || gy >= h || gx < 0) continue;
             for (int k = 0; k < 4 && gx + k < w; k++) out[(size_t)gy * w + gx + k] = s.y[row * POST_TW + 4 * g + k];
         }
@@ -571,8 +600,10 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
                 if (gy < 0 || gy >= ch) continue;
                 uint8_t *o = out + (size_t)w * h + (size_t)plane * cw * ch;
                 // the chroma strip origin is 2 mod 4: a group of 4 may straddle column 0
-                for (int k = 0; k < 4; k++)
-                    if (gx + k >= 0 && gx + k < cw) o[(size_t)gy * cw + gx + k] = s.c[plane][row * POST_CW + 4 * g + k];
+                for (int k = 0; k < 4; k++) {
+                    const int cx = post_wrap_cx(a, gx + k);            // (a group of 4 may straddle the wrap)
+                    if (cx >= 0 && cx < cw) o[(size_t)gy * cw + cx] = s.c[plane][row * POST_CW + 4 * g + k];
+                }
             }
         }
     }

@@ -131,7 +131,7 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
     a.planes_out = planes_out;
     a.n_pictures = n_pictures;
     a.strength = strength;
-    a.tiles_x = (a.L.width + POST_OX + POST_TW - 1) / POST_TW;
+    a.tiles_x = post_tile_columns(a.L.width, &a.wrap);      // as backend.cpp: set_post_tiles
     a.tiles_y = (post_strips_y(h) + POST_STRIPS - 1) / POST_STRIPS;
     a.luma_only = luma_only;
     PostStrip *s = (PostStrip *)aligned_alloc(16, (sizeof(PostStrip) + 15) / 16 * 16);
@@ -145,7 +145,7 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
         if (t >= chunk || wg >= wgs) continue;
         for (int wave = 0; wave < POST_GROUP; wave++) {
             const int pic = wg / wpp, rem = wg % wpp;
-            const int sx = rem % (int)a.tiles_x, ty = (rem / (int)a.tiles_x) * POST_GROUP + wave;
+            const int sx = rem % (int)a.tiles_x + (int)a.wrap, ty = (rem / (int)a.tiles_x) * POST_GROUP + wave;
             if (ty >= (int)a.tiles_y) continue;
             const int sy0 = ty * POST_STRIPS;
             // interior tiles take the instantiations without bounds handling, as on the device (kernels.hip: post_wave)

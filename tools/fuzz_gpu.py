@@ -27,8 +27,13 @@ def run(budget=60.0, seed=1, verbose=True):
     t_end = time.time() + budget
     n_pic = n_px = 0
     while time.time() < t_end:
-        w = int(rng.choice([rng.integers(1, 64), rng.integers(1, 420), 16 * rng.integers(1, 30), 176, 352]))
-        h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288]))
+        # (the last entries: sizes with several interior tiles of k_post per row and column, widths that are / are not
+        # multiples of 4 and 8 -- the wrap of the left picture columns into the last tile and the floor / truncation
+        # regions of the deblocking filter depend on them)
+        w = int(rng.choice([rng.integers(1, 64), rng.integers(1, 420), 16 * rng.integers(1, 30), 176, 352,
+                            rng.integers(260, 800), 4 * rng.integers(65, 200)]))
+        h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288,
+                            rng.integers(64, 420), 4 * rng.integers(16, 100)]))
         if rng.random() < 0.35:
             # through the bitstream: records -> test encoder -> h263mi_decode_next_picture (host parser, sparse transport)
             standard = bool(rng.integers(0, 2))

@@ -324,6 +324,10 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  * to parse, the error of the first such stream is returned and NOTHING changes for any stream.  Every picture must
  * have the batch's width and height.  The host parser is the bit-at-a-time reader of the reference (reader.rs:94-134,
  * 272-290) redesigned around a 64-bit window and table lookups (h263-rs_amd/host/bitstream.cpp).
+ * The host threads belong to the batch (created at the first call, parked between calls); the parser writes a stream's
+ * records straight into the pinned staging memory the copy to the device reads.  A batch is driven from one thread at a
+ * time.  With H263MI_TRACE_E2E set in the environment the batch prints, when it is destroyed, where the host time of
+ * these calls went (parser threads / waiting for a staging slot / packing / enqueueing).
  */
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads);

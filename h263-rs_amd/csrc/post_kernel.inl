@@ -148,17 +148,21 @@ H263_HD QuartetConsts quartet_consts(int strength, int tm)
     k.c1 = 0x00010001u & ~(uint32_t)tm;
     return k;
 }
+// FLOOR: both quartets lie where the reference divides with arithmetic shifts (every quartet of an interior tile): the
+// truncation biases are zero and their two additions are left out (written through the opaque packed helpers, "+ 0"
+// is not something the compiler can fold).
+template <bool FLOOR = false>
 H263_DEV void deblock_quartet_pk(uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D, const QuartetConsts &k)
 {
     const uint32_t adm = pk_sub_u16(A, D);
     const uint32_t x = pk_mad_i16(pk_sub_u16(C, B), 0x00040004u, adm);
-    const uint32_t d = pk_ashr_i16(pk_add_u16(x, pk_ashr_i16(x, 15) & k.c7), 3);
+    const uint32_t d = pk_ashr_i16(FLOOR ? x : pk_add_u16(x, pk_ashr_i16(x, 15) & k.c7), 3);
     const uint32_t sd = pk_ashr_i16(d, 15);                                   // 0 or -1 per half
     const uint32_t ad = pk_max_i16(d, pk_sub_u16(0u, d));                     // |d|
     const uint32_t mag = pk_max_i16(pk_min_i16(ad, pk_sub_u16(k.s2, ad)), 0u);   // up_down_ramp = median(0, |d|, 2S - |d|)
     const uint32_t d1 = pk_sub_u16(mag ^ sd, sd);
     const uint32_t lim = pk_lshr_u16(pk_add_u16(mag, sd & k.c1), 1);          // |d1 / 2| in the division of this position
-    const uint32_t q = pk_ashr_i16(pk_add_u16(adm, pk_ashr_i16(adm, 15) & k.c3), 2);
+    const uint32_t q = pk_ashr_i16(FLOOR ? adm : pk_add_u16(adm, pk_ashr_i16(adm, 15) & k.c3), 2);
     const uint32_t d2 = pk_max_i16(pk_min_i16(q, lim), pk_sub_u16(0u, lim));   // clipd1
     A = pk_sub_u16(A, d2);
     B = pk_add_u16(B, d1);
@@ -368,7 +372,7 @@ H263_DEV void hfilter2(uint8_t *t, int pitch, int row_a, int col, int strength, 
     // (an interior tile lies left of floor_cols altogether: floor division, constant biases)
     const QuartetConsts k = quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gx0, floor_cols));
     uint32_t A = bytes_to_pair(r[0], 0, 1), B = bytes_to_pair(r[1], 0, 1), C = bytes_to_pair(r[2], 0, 1), D = bytes_to_pair(r[3], 0, 1);
-    deblock_quartet_pk(A, B, C, D, k);
+    deblock_quartet_pk<INTERIOR>(A, B, C, D, k);
     uint32_t o[4] = {pair_low_bytes(A), sat_pk_u8_i16(B), sat_pk_u8_i16(C), pair_low_bytes(D)};
     if (!INTERIOR && edge_tile) {
         const uint32_t keep = (gx0 >= 0 && gx0 < w ? 0u : 0x00ffu) | (gx0 + 1 >= 0 && gx0 + 1 < w ? 0u : 0xff00u);
@@ -429,7 +433,7 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
             const uint64_t v0 = *p0, v1 = *p1;
             const uint32_t l0 = (uint32_t)v0, h0 = (uint32_t)(v0 >> 32), l1 = (uint32_t)v1, h1 = (uint32_t)(v1 >> 32);
             uint32_t A = bytes_to_pair2(l0, l1, 2), B = bytes_to_pair2(l0, l1, 3), C = bytes_to_pair2(h0, h1, 0), D = bytes_to_pair2(h0, h1, 1);
-            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
+            deblock_quartet_pk<INTERIOR>(A, B, C, D, quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
             // ab = [A'0, B'0, A'1, B'1], cd = [C'0, D'0, C'1, D'1] as bytes
             const uint32_t bs = sat_pk_u8_i16(B), cs = sat_pk_u8_i16(C);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -458,7 +462,7 @@ H263_DEV void post_phase_vedges(const PostArgs &a, PostStrip &s, int lane, int s
             uint32_t *p1 = reinterpret_cast<uint32_t *>(&s.c[plane][(row + 1) * POST_CW + 8 * j + 4]);
             const uint32_t v0 = *p0, v1 = *p1;
             uint32_t A = bytes_to_pair2(v0, v1, 0), B = bytes_to_pair2(v0, v1, 1), C = bytes_to_pair2(v0, v1, 2), D = bytes_to_pair2(v0, v1, 3);
-            deblock_quartet_pk(A, B, C, D, quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
+            deblock_quartet_pk<INTERIOR>(A, B, C, D, quartet_consts(strength, INTERIOR ? 0 : trunc_mask(gy < 0 ? gy + 1 : gy, (h / 8) * 8)));
             const uint32_t bs = sat_pk_u8_i16(B), cs = sat_pk_u8_i16(C);
 #if defined(__HIP_DEVICE_COMPILE__)
             const uint32_t ab = __builtin_amdgcn_perm(bs, A, 0x05020400u), cd = __builtin_amdgcn_perm(D, cs, 0x06010400u);

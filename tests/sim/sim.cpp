@@ -213,6 +213,16 @@ int sim_quartet_sweep(void (*ref)(uint8_t *, uint8_t *, uint8_t *, uint8_t *, ui
                             if (!bad) { first[0] = a0; first[1] = b0; first[2] = c0; first[3] = d0; first[4] = -strength; }
                             bad++;
                         }
+                        if (floor_sem) {
+                            // the instantiation of interior tiles (no truncation biases at all) must be the same function
+                            uint32_t fA = (uint32_t)a0 | ((uint32_t)d0 << 16), fB = (uint32_t)b0 | ((uint32_t)c0 << 16);
+                            uint32_t fC = (uint32_t)c0 | ((uint32_t)b0 << 16), fD = (uint32_t)d0 | ((uint32_t)a0 << 16);
+                            deblock_quartet_pk<true>(fA, fB, fC, fD, quartet_consts(strength, 0));
+                            if (fA != pA || fB != pB || fC != pC || fD != pD) {
+                                if (!bad) { first[0] = a0; first[1] = b0; first[2] = c0; first[3] = d0; first[4] = -100 - strength; }
+                                bad++;
+                            }
+                        }
                     }
     return bad;
 }

@@ -33,6 +33,7 @@ struct FrameGeom {
     uint32_t post_per_group;    // post tiles (waves) per group
     uint32_t inv_per_group;     // ceil(2^32 / (recon_per_group + post_per_group))
     uint32_t flip;              // walk the pictures of the batch in descending order
+    uint32_t bands;             // XCDs that share one picture (8, 4 or 2): 8 / bands pictures side by side
 };
 hipError_t launch_recon(const ReconArgs &args, hipStream_t stream);
 // k_recon over `rargs` and k_post over `pargs` (same number of pictures, same picture size) as ONE launch.

@@ -313,14 +313,20 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
     const int lane = threadIdx.x & 63;
     const uint32_t per_group = fg.recon_per_group + fg.post_per_group;
     const uint32_t upp = fg.groups * per_group;
-    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
-    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
-    if (t >= chunk || g >= upp) return;
+    // A picture's work list is dealt to `bands` XCDs in contiguous chunks, 8 / bands pictures side by side (fg.bands:
+    // 8, 4 or 2; blockIdx.y counts sets of 8 / bands pictures).  Fewer, taller bands: fewer band borders, whose
+    // reference rows two L2s fetch.
+    const uint32_t bands = fg.bands, xcd = blockIdx.x & 7;
+    const uint32_t chunk = (upp + bands - 1) / bands, band = xcd & (bands - 1), side = xcd / bands;
+    const uint32_t t = blockIdx.x >> 3, g = band * chunk + t;
+    const uint32_t pic_y = blockIdx.y * (8 / bands) + side;
+    if (t >= chunk || g >= upp || pic_y >= ra.n_pictures) return;
     const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group);
     const uint32_t r = g - group * per_group;      // (post tiles in front of the reconstruction sub-tiles: no difference)
+    const int pic = fg.flip ? (int)(ra.n_pictures - 1 - pic_y) : (int)pic_y;
     if (r < fg.recon_per_group) {
         WavePos p;
-        p.pic = fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+        p.pic = pic;
         p.mbx0 = (int)(r >> 2) * TILE_MBX;
         p.mby = (int)group * TILE_MBY + (int)((r >> 1) & 1);
         p.half = (int)(r & 1);
@@ -328,8 +334,7 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
         recon_wave(ra, lds.r, lane, p);
     } else {
         if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
-        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group,
-                        fg.flip ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y);
+        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic);
     }
 }
 
@@ -346,12 +351,21 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
     if ((uint64_t)fg.groups * per_group >= (1u << 24)) return hipErrorInvalidValue;
     fg.inv_per_group = reciprocal_u32(per_group);
     fg.flip = descending ? 1u : 0u;
+#ifndef H263MI_FRAME_BANDS
+#define H263MI_FRAME_BANDS 4
+#endif
+    // Bands per picture.  Measured on the 64-stream bench (rocprofv3 FETCH_SIZE, A/B of six rounds): 8 bands fetch
+    // 372 MB per launch, 4 bands 341 MB and run 3 % faster, 2 bands 326 MB (the algorithmic reads are 317 MB) but run
+    // no faster than 8, 1 band (a picture per XCD) is 4 % slower.  Small batches keep 8 bands: with fewer, 8 / bands
+    // pictures are needed to occupy every XCD.
+    fg.bands = rargs.n_pictures >= 16 ? H263MI_FRAME_BANDS : 8u;
     ReconArgs ra = rargs;
     PostArgs pa = pargs;
     ra.inv_tiles_x = reciprocal_u32(rargs.tiles_x);
     pa.inv_tiles_x = reciprocal_u32(pargs.tiles_x);
-    const uint32_t chunk = (fg.groups * per_group + 7) / 8;
-    hipLaunchKernelGGL(k_frame, dim3(chunk * 8, rargs.n_pictures), dim3(64), 0, stream, ra, pa, fg);
+    const uint32_t chunk = (fg.groups * per_group + fg.bands - 1) / fg.bands, side_by_side = 8 / fg.bands;
+    hipLaunchKernelGGL(k_frame, dim3(chunk * 8, (rargs.n_pictures + side_by_side - 1) / side_by_side), dim3(64), 0, stream, ra,
+                       pa, fg);
     return hipGetLastError();
 }
 

@@ -168,20 +168,32 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     // No integer division on the device: the only one left, by tiles_x, is a multiply-high with a host-made reciprocal.
     constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES / RECON_WAVES;
     const uint32_t upp = a.tiles_x * a.tiles_y * kUnitsPerTile;           // work items of one picture
-    const uint32_t chunk = (upp + 7) / 8, xcd = blockIdx.x & 7;
-    const uint32_t t = blockIdx.x >> 3, g = xcd * chunk + t;
-    if (t >= chunk || g >= upp) return;
+    // a picture's list is dealt to a.bands XCDs in contiguous chunks, 8 / a.bands pictures side by side (see k_frame)
+    const uint32_t bands = a.bands, xcd = blockIdx.x & 7;
+    const uint32_t chunk = (upp + bands - 1) / bands, t = blockIdx.x >> 3, g = (xcd & (bands - 1)) * chunk + t;
+    const uint32_t pic = blockIdx.y * (8 / bands) + xcd / bands;
+    if (t >= chunk || g >= upp || pic >= a.n_pictures) return;
     const uint32_t tile = g / kUnitsPerTile;                               // power of two
     const int tw = ((int)(g % kUnitsPerTile) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
     const uint32_t tile_y = div_tiles_x(tile, a.tiles_x, a.inv_tiles_x), tile_x = tile - tile_y * a.tiles_x;
     WavePos p;
-    p.pic = (int)blockIdx.y;
+    p.pic = (int)pic;
     p.mbx0 = (int)tile_x * TILE_MBX;
     p.mby = (int)tile_y * TILE_MBY + (tw >> 1);
     p.half = tw & 1;
     p.cbase = 0;
     recon_wave(a, waves[wave], lane, p);
 }
+
+// Bands per picture: the XCDs that share one picture's work list (k_recon, k_frame).  Measured on the 64-stream bench
+// with k_frame (rocprofv3 FETCH_SIZE, A/Bs of six rounds): 8 bands fetch 372 MB per launch, 4 bands 341 MB and run
+// 1.5-3 % faster (fewer band borders, whose reference rows two L2s fetch), 2 bands 326 MB (the algorithmic reads are
+// 317 MB) but run no faster than 8, 1 band (a picture per XCD) is 4 % slower.  Small batches keep 8 bands: with fewer,
+// 8 / bands pictures are needed to occupy every XCD.
+#ifndef H263MI_FRAME_BANDS
+#define H263MI_FRAME_BANDS 4
+#endif
+static uint32_t frame_bands(uint32_t n_pictures) { return n_pictures >= 16 ? H263MI_FRAME_BANDS : 8u; }
 
 // ceil(2^32 / d): n / d == mul_hi(n, r) for n * d < 2^32
 static uint32_t reciprocal_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
@@ -193,8 +205,10 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
     ReconArgs a = args;
     a.inv_tiles_x = reciprocal_u32(args.tiles_x);
     const uint32_t upp = args.tiles_x * args.tiles_y * (TILE_WAVES / RECON_HALVES / RECON_WAVES);
-    const uint32_t chunk = (upp + 7) / 8;
-    hipLaunchKernelGGL(k_recon, dim3(chunk * 8, args.n_pictures), dim3(RECON_THREADS), 0, stream, a);
+    a.bands = frame_bands(args.n_pictures);
+    const uint32_t chunk = (upp + a.bands - 1) / a.bands, side_by_side = 8 / a.bands;
+    hipLaunchKernelGGL(k_recon, dim3(chunk * 8, (args.n_pictures + side_by_side - 1) / side_by_side), dim3(RECON_THREADS), 0,
+                       stream, a);
     return hipGetLastError();
 }
 
@@ -351,14 +365,7 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
     if ((uint64_t)fg.groups * per_group >= (1u << 24)) return hipErrorInvalidValue;
     fg.inv_per_group = reciprocal_u32(per_group);
     fg.flip = descending ? 1u : 0u;
-#ifndef H263MI_FRAME_BANDS
-#define H263MI_FRAME_BANDS 4
-#endif
-    // Bands per picture.  Measured on the 64-stream bench (rocprofv3 FETCH_SIZE, A/B of six rounds): 8 bands fetch
-    // 372 MB per launch, 4 bands 341 MB and run 3 % faster, 2 bands 326 MB (the algorithmic reads are 317 MB) but run
-    // no faster than 8, 1 band (a picture per XCD) is 4 % slower.  Small batches keep 8 bands: with fewer, 8 / bands
-    // pictures are needed to occupy every XCD.
-    fg.bands = rargs.n_pictures >= 16 ? H263MI_FRAME_BANDS : 8u;
+    fg.bands = frame_bands(rargs.n_pictures);
     ReconArgs ra = rargs;
     PostArgs pa = pargs;
     ra.inv_tiles_x = reciprocal_u32(rargs.tiles_x);

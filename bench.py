@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="strong scaling (SURVEY 8d config 5, second form): this many streams in total, split evenly over "
+                         "the GPUs; 0 = off (weak scaling, --streams per GPU)")
     ap.add_argument("--gop", type=int, default=GOP)
     ap.add_argument("--gops-per-step", type=int, default=GOPS_PER_STEP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -360,7 +363,8 @@ def stub_main(args, rank, world):
     else:
         dist = None
     elapsed = shard.timed_region(dist, lambda: time.sleep(0.01 * args.steps))
-    pictures = shard.aggregate_pictures(dist, args.streams * args.steps * args.gop * args.gops_per_step)
+    per_rank = args.total_streams // world if args.total_streams else args.streams
+    pictures = shard.aggregate_pictures(dist, per_rank * args.steps * args.gop * args.gops_per_step)
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": pictures * MP_PER_PICTURE / elapsed, "unit": "MP/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "data": "stub (no GPU work)",
@@ -405,8 +409,11 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
     stream = torch.cuda.current_stream().cuda_stream
-    n = args.streams
-    my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU
+    strong = args.total_streams > 0
+    if strong and args.total_streams % world:
+        raise SystemExit("--total-streams %d is not a multiple of %d GPUs" % (args.total_streams, world))
+    n = args.total_streams // world if strong else args.streams
+    my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU; strong: total / GPUs
     wl = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream)
     pipeline = not args.no_pipeline and not args.overlap
     batch = h263mi.Batch(n, W, H, local_rank, stream, overlap_post=args.overlap, pipeline_post=pipeline)
@@ -557,7 +564,8 @@ def main(argv=None):
     out = {
         "metric": "decoded megapixels/sec (IDCT+MC+YUV->RGB)",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u8/i16/i32 integer + f32 (IDCT, un-fused)", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: batch of %d independent 1920x1080 streams per GPU; step = one pass "
                                "over the resident input = %d GOPs x %d frame indices = %d pictures per stream (%d per "

@@ -50,22 +50,24 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 #else
 #define ISA_MARK(name) do { } while (0)
 #endif
+// the same inside code that exists in two instantiations: the marker says which one
+#define ISA_MARK2(first, prefix_a, prefix_b, name) do { if (first) ISA_MARK(prefix_a name); else ISA_MARK(prefix_b name); } while (0)
 
 // ---------------------------------------------------------------------------------------
 // k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
 // workgroup, tiles taken in XCD-aware order (see k_post below).
 // ---------------------------------------------------------------------------------------
 // One IDCT round of a wave: 8 blocks, 8 lanes each.
-template <bool FIRST>
+template <bool FIRST, bool MC>
 __device__ __forceinline__ void recon_round(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
                                             int round, const WaveMasks &km)
 {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     RowIn ri;
-    ISA_MARK("round_begin");
+    ISA_MARK2(MC, "mc_", "intra_", "round_begin");
     recon_phase_idct_load(a, s, f, ln, p, FIRST ? 0 : round, ri, km);
-    ISA_MARK("idct_load_end");
+    ISA_MARK2(MC, "mc_", "intra_", "idct_load_end");
     // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
     const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
                         (__ballot(ri.w[3] != 0) ? 8u : 0u);
@@ -79,9 +81,9 @@ __device__ __forceinline__ void recon_round(const ReconArgs &a, ReconWave &s, co
     const bool any_special = __ballot(recon_block_is_special(ri, ln, rows_any, cols_any)) != 0;
     asm volatile("" : "+v"(ln));
     wave_fence();                           // the row pass results are in LDS
-    ISA_MARK("idct_rows_end");
+    ISA_MARK2(MC, "mc_", "intra_", "idct_rows_end");
     recon_phase_idct_cols(s, ri, ln, rows_from_mask(rows_mask & 0xffu), rows_any, cols_any, any_special);
-    ISA_MARK("idct_cols_end");
+    ISA_MARK2(MC, "mc_", "intra_", "idct_cols_end");
 }
 
 // fetch -> IDCT rounds -> output of one sub-tile.  MC: some macroblock of the wave takes a prediction.
@@ -90,19 +92,20 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
                                            unsigned long long &t_prev_)
 {
     (void)t_prev_;                                  // (only the diagnosis build H263MI_PROFILE_PHASES reads the clock)
+    ISA_MARK2(MC, "mc_", "intra_", "tail_begin");
     int ln = lane;
     WaveFetch f;
     recon_phase_fetch<MC>(a, s, f, ln, p, km);      // every global load of this half is in flight from here
     const int n_active = recon_n_active(km);
-    ISA_MARK("fetch_end");
+    ISA_MARK2(MC, "mc_", "intra_", "fetch_end");
     PHASE_MARK(2);
     // The first round is peeled off the loop: its coefficient row was requested by the fetch phase, ahead of the
     // reference rows, and straight-line code is what lets the compiler wait for exactly that load
     // (s_waitcnt vmcnt(6)) and leave the six reference loads in flight under the IDCT.  Inside the loop the
     // per-round coefficient load makes every wait a vmcnt(0).
-    if (n_active > 0) recon_round<true>(a, s, f, ln, p, 0, km);
+    if (n_active > 0) recon_round<true, MC>(a, s, f, ln, p, 0, km);
 #pragma unroll 1
-    for (int round = 1; round * ROUND_BLOCKS < n_active; round++) recon_round<false>(a, s, f, ln, p, round, km);
+    for (int round = 1; round * ROUND_BLOCKS < n_active; round++) recon_round<false, MC>(a, s, f, ln, p, round, km);
     PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
 #if defined(H263MI_PROFILE_PHASES)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -110,9 +113,9 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
 #endif
     asm volatile("" : "+v"(ln));
     wave_fence();                               // the residual strip is complete
-    ISA_MARK("output_begin");
+    ISA_MARK2(MC, "mc_", "intra_", "output_begin");
     recon_phase_output<MC>(a, s, f, ln, p, km);
-    ISA_MARK("output_end");
+    ISA_MARK2(MC, "mc_", "intra_", "output_end");
 }
 
 // One wave's share of the reconstruction: the sub-tile(s) at `p` (RECON_HALVES of them, p.half counting up).
@@ -229,23 +232,23 @@ __device__ __forceinline__ void post_strip(const PostArgs &a, PostStrip &s, Post
     // the whole kernel -- the hoisted form cost half of the occupancy.
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    ISA_MARK("strip_begin");
+    ISA_MARK2(INTERIOR, "interior_", "edge_", "strip_begin");
     wave_fence();                                   // the previous strip has been read out of LDS
     post_phase_commit<INTERIOR>(a, s, pf, ln);
-    ISA_MARK("commit_end");
+    ISA_MARK2(INTERIOR, "interior_", "edge_", "commit_end");
     if (FETCH_AHEAD) post_phase_fetch<INTERIOR>(a, pf, ln, sx, sy + 2, pic);
-    ISA_MARK("fetch_end");
+    ISA_MARK2(INTERIOR, "interior_", "edge_", "fetch_end");
     wave_fence();                                   // the strip is in LDS
     if (a.strength) {
         post_phase_hedges<INTERIOR>(a, s, ln, sx, sy);
         wave_fence();
-        ISA_MARK("hedges_end");
+        ISA_MARK2(INTERIOR, "interior_", "edge_", "hedges_end");
         post_phase_vedges<INTERIOR>(a, s, ln, sx, sy);
         wave_fence();
-        ISA_MARK("vedges_end");
+        ISA_MARK2(INTERIOR, "interior_", "edge_", "vedges_end");
     }
     post_phase_store<STREAM_RGBA, INTERIOR>(a, s, ln, sx, sy, pic);
-    ISA_MARK("store_end");
+    ISA_MARK2(INTERIOR, "interior_", "edge_", "store_end");
 }
 
 // Two strips of a tile.  FETCH_AHEAD: queue the loads of the strips two further down right after each
@@ -268,6 +271,7 @@ template <bool STREAM_RGBA, bool INTERIOR>
 __device__ __forceinline__ void post_tile(const PostArgs &a, PostStrip &s, int lane, int sx, int ty, int pic)
 {
     const int sy0 = ty * POST_STRIPS;
+    ISA_MARK2(INTERIOR, "interior_", "edge_", "tile_begin");
     // (The edge-tile instantiation is 5 700 instructions, half of k_frame, for 18 % of the tiles.  As a loop over the
     // strips with one copy of the strip code k_frame shrinks from 12 100 to 7 700 lines of assembly and runs exactly as
     // fast, dense I pictures 1 % slower: the instruction cache is not what limits it; the unrolled form stays.)

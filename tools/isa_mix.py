@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static per-phase instruction mix of a gfx950 kernel, from the compiler's assembly.
 
-    python tools/isa_mix.py [k_recon|k_post] [-D MACRO ...] > profiles/rNN_isa_mix_<kernel>.txt
+    python tools/isa_mix.py [k_recon|k_post|k_frame] [-D MACRO ...] > profiles/rNN_isa_mix_<kernel>.txt
 
 Builds h263-rs_amd/csrc/kernels.hip for the device only with -DH263MI_ISA_MARKERS (comments at the phase
 boundaries, no instruction emitted) and counts, per phase, the instructions between two markers in program order:
@@ -11,6 +11,10 @@ boundaries, no instruction emitted) and counts, per phase, the instructions betw
   valu_slow  every other VALU opcode (~4.2-4.6 cycles: v_perm, v_med3, v_bfe, v_cndmask, v_cmp, cvt, 24-bit
              multiplies, all v_pk_*, SDWA/DPP forms, v_lshlrev, v_lerp_u8, v_alignbyte ...)
   salu / smem / lds / vmem_rd / vmem_wr / wait (s_waitcnt, s_nop) / branch
+
+Code that exists in two instantiations carries the instantiation in the marker: interior_ / edge_ (tiles of k_post
+without / with bounds handling), mc_ / intra_ (reconstruction waves with / without a prediction to fetch); a phase that
+the compiler unrolled (the four strips of a post tile) is summed over its copies, `copies` says how many.
 
 Basic blocks that hold the picture-border tap gather of k_recon (recognised by v_lshrrev_b64, which occurs nowhere
 else) are reported separately as `border`: one wave in 8-12 executes them on the bench workload.  The table is
@@ -26,7 +30,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_ashrrev_i32",
         "v_mov_b32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_fma_f32", "v_fmac_f32", "v_not_b32"}
-MANGLED = {"k_recon": "_ZN6h263mi7k_reconENS_9ReconArgsE", "k_post": "_ZN6h263mi6k_postENS_8PostArgsE"}
+MANGLED = {"k_recon": "_ZN6h263mi7k_reconENS_9ReconArgsE", "k_post": "_ZN6h263mi6k_postENS_8PostArgsE",
+           "k_frame": "_ZN6h263mi7k_frameENS_9ReconArgsENS_8PostArgsENS_9FrameGeomE"}
 CLASSES = ["valu_fast", "valu_slow", "salu", "smem", "lds", "vmem_rd", "vmem_wr", "wait", "branch"]
 
 
@@ -73,7 +78,8 @@ def main():
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     name = MANGLED[kernel]
-    body = re.split(r"\n%s:[^\n]*\n" % re.escape(name), text, maxsplit=1)[1].split("s_endpgm", 1)[0].splitlines()
+    # (up to the end of the function: a kernel with several exits has several s_endpgm)
+    body = re.split(r"\n%s:[^\n]*\n" % re.escape(name), text, maxsplit=1)[1].split(".Lfunc_end", 1)[0].splitlines()
     meta = re.search(r"\.name:\s+%s\n(.*?)\.wavefront_size" % re.escape(name), text, re.S).group(1)
 
     # split into basic blocks, remember the phase each instruction belongs to
@@ -104,7 +110,12 @@ def main():
 
     table = collections.OrderedDict()
     opcount = collections.Counter()
+    copies = collections.Counter()
+    last = None
     for ph, ops in blocks:
+        if ph != last:
+            copies[ph] += 1
+            last = ph
         border = sum(o.startswith("v_lshrrev_b64") for o in ops) >= 4
         row = table.setdefault(ph, {"main": collections.Counter(), "border": collections.Counter()})
         for o in ops:
@@ -117,16 +128,16 @@ def main():
         m = re.search(r"\.%s:\s+(\d+)" % k, meta)
         if m:
             print("# %s = %s" % (k, m.group(1)))
-    hdr = "%-22s" % "phase" + "".join("%10s" % c for c in CLASSES) + "%10s" % "border*"
+    hdr = "%-30s" % "phase" + "".join("%10s" % c for c in CLASSES) + "%10s" % "border*" + "%8s" % "copies"
     print(hdr)
     tot = collections.Counter()
     tot_border = 0
     for ph, row in table.items():
         nb = sum(row["border"].values())
-        print("%-22s" % ph + "".join("%10d" % row["main"][c] for c in CLASSES) + "%10d" % nb)
+        print("%-30s" % ph + "".join("%10d" % row["main"][c] for c in CLASSES) + "%10d" % nb + "%8d" % copies[ph])
         tot.update(row["main"])
         tot_border += nb
-    print("%-22s" % "total" + "".join("%10d" % tot[c] for c in CLASSES) + "%10d" % tot_border)
+    print("%-30s" % "total" + "".join("%10d" % tot[c] for c in CLASSES) + "%10d" % tot_border)
     print("# border* = all instructions of the basic blocks that gather picture-edge taps (executed by the waves that\n"
           "#           touch the left / right picture edge only); not included in the other columns")
     print("# most frequent opcodes outside the border blocks:")

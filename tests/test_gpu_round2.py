@@ -283,7 +283,10 @@ def test_batch_decode_next_pictures_from_bitstreams():
 # H263MI_CFG_PIPELINE_POST: reconstruction of picture f and post-processing of picture f-1 in one launch (k_frame)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("w,h,n", [(176, 144, 3), (100, 60, 2), (33, 17, 1), (352, 288, 2), (1920, 1080, 2), (64, 36, 2),
-                                   (48, 32, 2), (1, 1, 3), (16, 16, 1), (2000, 64, 1)])
+                                   (48, 32, 2), (1, 1, 3), (16, 16, 1), (2000, 64, 1),
+                                   # 16 pictures and more: a picture is dealt to 4 XCDs, two pictures side by side
+                                   # (an odd count leaves the last pair half empty)
+                                   (176, 144, 17), (100, 60, 16), (48, 32, 33), (352, 288, 19)])
 def test_pipelined_batch_gives_the_same_pictures(w, h, n):
     """every picture's planes, RGBA and filtered planes against the oracle; the mode mixes with the immediate calls
     (submit / render_rgba), with reset, and an I picture in the middle of the chain"""

@@ -1,3 +1,8 @@
+#!/bin/bash
+# HBM traffic of k_frame for 8 / 4 / 2 bands per picture (profiles/r02_k_traffic_by_bands.txt): separate rocprofv3 --pmc
+# FETCH_SIZE / WRITE_SIZE passes over a short bench run per build.  The builds are variants of the library,
+#   hipcc <flags of h263-rs_amd/Makefile> -DH263MI_FRAME_BANDS=<8|4|2> ... -o h263-rs_amd/variants/lib_b<8|4|2>.so
+# usage (GPU box, repo root): bash tools/probes/pmc_bands.sh
 R=$PWD; OUT=$R/gpurun_out/s2/pmc_bands; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for L in b8 b4 b2; do
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -26,7 +26,7 @@ class Shifted:
         self.ptr = ptr
 
 
-for off in (0, 4096, 8192, 16384, 65536, 1 << 20, (1 << 20) + 4096, 2 << 20, 3 << 20, 7 << 20, 33 << 20, 0):
+for off in ([int(a) for a in sys.argv[1:]] or [0, 4096, 8192, 16384, 65536, 1 << 20, (1 << 20) + 4096, 2 << 20, 3 << 20, 7 << 20, 33 << 20, 0]):
     buf = Shifted(rgba.ptr.value + off)
     bench.run_frames(batch, wl, buf, GOP, True)
     batch.sync()

@@ -276,7 +276,7 @@ def cpu_baseline(h263mi, budget_s=12.0):
 # ---------------------------------------------------------------------------------------------------------------
 # end to end: Sorenson Spark bitstreams -> host parser threads -> events over PCIe -> k_expand, k_recon, k_post
 # ---------------------------------------------------------------------------------------------------------------
-def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8, gop=GOP):
+def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8, gop=GOP, parser_threads=None):
     """The north star's end-to-end figure (never the headline `value`: the host parser and the PCIe link are in it).
     n streams of 1920x1080 Sorenson Spark pictures (the bench workload's records serialised by the test encoder,
     tests/sorenson_enc.py; `n_distinct` different streams, repeated), one h263mi_batch_decode_next_pictures +
@@ -301,7 +301,7 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
         streams.append(pics)
         recs.append(rr)
     t_enc = time.perf_counter() - t_enc
-    cores = physical_cores()[0]
+    cores = parser_threads or physical_cores()[0]
     batch = h263mi.Batch(n, W, H, device_id, stream)
     prepared = [batch.prepare_pictures([streams[s % n_distinct][f] for s in range(n)]) for f in range(n_frames)]
 

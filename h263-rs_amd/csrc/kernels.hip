@@ -327,7 +327,12 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg)
 {
+#if defined(H263MI_LDS_PAD)
+    // experiment: what a larger LDS footprint per wave (fewer resident waves) costs
+    __shared__ __attribute__((aligned(16))) union { ReconWave r; PostStrip p; uint8_t pad[H263MI_LDS_PAD]; } lds;
+#else
     __shared__ __attribute__((aligned(16))) union { ReconWave r; PostStrip p; } lds;
+#endif
     const int lane = threadIdx.x & 63;
     const uint32_t per_group = fg.recon_per_group + fg.post_per_group;
     const uint32_t upp = fg.groups * per_group;

@@ -58,7 +58,11 @@ constexpr int WAVE_TASKS = 24;                 // 16 luma + 8 chroma blocks per 
 constexpr int ROUND_BLOCKS = 8;                // blocks per IDCT round (8 lanes each)
 constexpr int TBUF_ROW = 8;                    // floats per row of a block slot: T[r][0..7], written as two 16-byte stores
 constexpr int TBUF_STRIDE = 8 * TBUF_ROW + 8;  // 72 floats per slot: 8 pad floats make the column reads bank-conflict free
+#if defined(H263MI_TIMING_RES_STRIDE)
+constexpr int RES_STRIDE = H263MI_TIMING_RES_STRIDE;   // TIMING EXPERIMENT ONLY (rows overlap, results wrong): a smaller LDS footprint
+#else
 constexpr int RES_STRIDE = 192;                // residual strip row: 128 luma + 64 chroma columns
+#endif
 
 struct ReconWave {
     uint32_t rec[TILE_MBX][8];                 // the 8 records as dwords: [0] mb_type | quant << 8 | cbp << 16 | kill << 24,
@@ -66,7 +70,7 @@ struct ReconWave {
     uint32_t mvc[TILE_MBX];                    // chroma vector per macroblock, x | y << 16 (gather.rs:182)
     uint32_t desc[WAVE_TASKS][2];              // descriptors of the active tasks, compacted (see TaskInfo)
     float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results T[r][i] of the round's 8 blocks
-    int16_t  res[8 * RES_STRIDE];              // residual strip: 8 rows x (128 luma | 64 chroma) columns
+    int16_t  res[7 * RES_STRIDE + 192];        // residual strip: 8 rows x (128 luma | 64 chroma) columns
 };
 static_assert(sizeof(MbRecord) == 32 && offsetof(MbRecord, mv) == 4 && offsetof(MbRecord, intradc) == 20 &&
               offsetof(MbRecord, coeff_index) == 28, "record words used by the mark phase");

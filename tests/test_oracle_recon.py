@@ -209,3 +209,41 @@ def test_kill_bit_discards_block_and_dc():
     Y = y.reshape(16, 16)
     assert (Y[:8, :8] == 0).all() and (Y[8:, :8] == 0).all()       # blocks 0 and 2 are Zero
     assert Y[:8, 8:].any() and Y[8:, 8:].any()
+
+
+def test_named_vert_columns_golden_file():
+    """tests/golden/vert_named_columns.json (tools/gen_vert_columns.py): reachable first-coefficient columns on which the
+    Vert class and the Full arithmetic differ; the C oracle (through the whole record path: LEVELs at quantiser 1 ->
+    inverse_rle -> idct_channel), the numpy restatement and the soft-float model must all give the file's `vert` rows.
+    tests/test_gpu_round3.py decodes the same columns on the MI355X."""
+    import json
+    import os
+    from oracle import softfloat_idct as sf
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vert_named_columns.json")
+    gold = json.load(open(path))["columns"]
+    assert len(gold) >= 5 and gold[0]["column"] == [19, 0, 0, 0, -7, 0, 0, 0]        # SURVEY appendix B.2
+    for g in gold:
+        col = g["column"]
+        assert all(v == 0 or v % 2 for v in col)               # rle.rs:130-133 only produces odd values
+        # the record path: a P macroblock at quantiser 1 whose block 0 carries the LEVELs, over a flat prediction
+        mbs = np.zeros(1, orc.MB_RECORD_DTYPE)
+        mbs["quant"] = 1
+        mbs["cbp"] = 1
+        co = np.zeros((1, 64), np.int16)
+        for r, level in g["levels_at_quant_1"].items():
+            co[0, 8 * int(r)] = level
+            assert sf.dequant(level, 1) == col[int(r)]
+        ref = (np.full(256, 100, np.uint8), np.full(64, 100, np.uint8), np.full(64, 100, np.uint8))
+        rc, out = orc.decode_picture(16, 16, mbs, co, ref)
+        assert rc == 0
+        rows = out[0].reshape(16, 16)[:8, :8].astype(int) - 100
+        assert (rows == np.array(g["vert"])[:, None]).all(), col
+        dense = np.zeros((8, 8), np.float32)
+        dense[:, 0] = col
+        assert npr.idct_residual(npr.VERT, dense)[:, 0].tolist() == g["vert"]
+        assert _full_path(dense)[:, 0].tolist() == g["full"]
+        block = [0] * 64
+        for r, v in enumerate(col):
+            block[8 * r] = v
+        assert [row[0] for row in sf.block_residual(block)] == g["vert"]
+        assert [row[0] for row in sf.block_residual(block, force_full=True)] == g["full"]

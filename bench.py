@@ -406,7 +406,9 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; rank / world size are passed explicitly so that the forced single-rank form needs no
+        # launcher environment
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     stream = torch.cuda.current_stream().cuda_stream
     strong = args.total_streams > 0

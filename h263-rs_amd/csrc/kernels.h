@@ -29,7 +29,7 @@ hipError_t launch_expand(const ExpandArgs &args, hipStream_t stream);
 // geometry of the merged launch (k_frame), made by its launcher
 struct FrameGeom {
     uint32_t groups;            // groups of 32 luma rows per picture
-    uint32_t recon_per_group;   // reconstruction sub-tiles (waves) per group: 4 per 8x2-macroblock tile
+    uint32_t recon_per_group;   // reconstruction waves per group: 2 per 8x2-macroblock tile (one per macroblock row)
     uint32_t post_per_group;    // post tiles (waves) per group
     uint32_t inv_per_group;     // ceil(2^32 / (recon_per_group + post_per_group))
     uint32_t flip;              // walk the pictures of the batch in descending order

@@ -54,39 +54,56 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 #define ISA_MARK2(first, prefix_a, prefix_b, name) do { if (first) ISA_MARK(prefix_a name); else ISA_MARK(prefix_b name); } while (0)
 
 // ---------------------------------------------------------------------------------------
-// k_recon: 256 threads = 4 independent waves (no workgroup barrier), one 8x2-macroblock tile per
-// workgroup, tiles taken in XCD-aware order (see k_post below).
+// k_recon: one wave = 8 whole macroblocks (recon_kernel.inl), no workgroup barrier, work taken in XCD-aware order
+// (see k_post below).
 // ---------------------------------------------------------------------------------------
-// One IDCT round of a wave: 8 blocks, 8 lanes each.
+// One IDCT round of a wave: 8 blocks, 8 lanes each.  The row pass and the column pass are separate calls because the
+// first round runs its row pass BEFORE the prediction is written to the strip (under the reference loads) and its
+// column pass after it.
+struct RoundState {
+    RowIn ri;
+    uint64_t rows_any, cols_any;        // ballots of the row classes (recon_row_class)
+    uint32_t rows_mask;                 // bit r: some block of the round has something in coefficient row r
+    bool any_special;                   // some block of the round is Vert, Dc or Zero
+};
+
 template <bool FIRST, bool MC>
-__device__ __forceinline__ void recon_round(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
-                                            int round, const WaveMasks &km)
+__device__ __forceinline__ void recon_round_rows(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
+                                                 int round, const WaveMasks &km, RoundState &rs)
 {
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    RowIn ri;
     ISA_MARK2(MC, "mc_", "intra_", "round_begin");
-    recon_phase_idct_load(a, s, f, ln, p, FIRST ? 0 : round, ri, km);
+    recon_phase_idct_load(a, s, f, ln, p, FIRST ? 0 : round, rs.ri, km);
     ISA_MARK2(MC, "mc_", "intra_", "idct_load_end");
     // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
-    const uint32_t wm = (__ballot(ri.w[1] != 0) ? 2u : 0u) | (__ballot(ri.w[2] != 0) ? 4u : 0u) |
-                        (__ballot(ri.w[3] != 0) ? 8u : 0u);
-    const RowClass rc = recon_row_class(ri, ln);
-    const uint64_t rows_any = __ballot(rc.any), cols_any = __ballot(rc.beyond_first);      // bit slot*8 + row
+    const uint32_t wm = (__ballot(rs.ri.w[1] != 0) ? 2u : 0u) | (__ballot(rs.ri.w[2] != 0) ? 4u : 0u) |
+                        (__ballot(rs.ri.w[3] != 0) ? 8u : 0u);
+    const RowClass rc = recon_row_class(rs.ri, ln);
+    rs.rows_any = __ballot(rc.any);
+    rs.cols_any = __ballot(rc.beyond_first);                          // bit slot*8 + row
     wave_fence();                           // the column pass of the previous round has read tbuf
-    recon_phase_idct_rows(s, ri, ln, cols_from_mask(wm), cols_any);
-    uint32_t rows_mask = (uint32_t)rows_any | (uint32_t)(rows_any >> 32);
+    recon_phase_idct_rows(s, rs.ri, ln, cols_from_mask(wm), rs.cols_any);
+    uint32_t rows_mask = (uint32_t)rs.rows_any | (uint32_t)(rs.rows_any >> 32);
     rows_mask |= rows_mask >> 16;
     rows_mask |= rows_mask >> 8;
-    const bool any_special = __ballot(recon_block_is_special(ri, ln, rows_any, cols_any)) != 0;
-    asm volatile("" : "+v"(ln));
+    rs.rows_mask = rows_mask & 0xffu;
+    rs.any_special = __ballot(recon_block_is_special(rs.ri, ln, rs.rows_any, rs.cols_any)) != 0;
     wave_fence();                           // the row pass results are in LDS
     ISA_MARK2(MC, "mc_", "intra_", "idct_rows_end");
-    recon_phase_idct_cols(s, ri, ln, rows_from_mask(rows_mask & 0xffu), rows_any, cols_any, any_special);
+}
+
+template <bool MC>
+__device__ __forceinline__ void recon_round_cols(ReconWave &s, int lane, const RoundState &rs)
+{
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    recon_phase_idct_cols(s, rs.ri, ln, rows_from_mask(rs.rows_mask), rs.rows_any, rs.cols_any, rs.any_special);
     ISA_MARK2(MC, "mc_", "intra_", "idct_cols_end");
 }
 
-// fetch -> IDCT rounds -> output of one sub-tile.  MC: some macroblock of the wave takes a prediction.
+// fetch -> row pass of the first round -> prediction into the strip -> column pass -> remaining rounds -> store.
+// MC: some macroblock of the wave takes a prediction.
 template <bool MC>
 __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, const WaveMasks &km,
                                            unsigned long long &t_prev_)
@@ -95,30 +112,37 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     ISA_MARK2(MC, "mc_", "intra_", "tail_begin");
     int ln = lane;
     WaveFetch f;
-    recon_phase_fetch<MC>(a, s, f, ln, p, km);      // every global load of this half is in flight from here
+    recon_phase_fetch<MC>(a, s, f, ln, p, km);      // every global load of this wave is in flight from here
     const int n_active = recon_n_active(km);
     ISA_MARK2(MC, "mc_", "intra_", "fetch_end");
     PHASE_MARK(2);
     // The first round is peeled off the loop: its coefficient row was requested by the fetch phase, ahead of the
     // reference rows, and straight-line code is what lets the compiler wait for exactly that load
-    // (s_waitcnt vmcnt(6)) and leave the six reference loads in flight under the IDCT.  Inside the loop the
-    // per-round coefficient load makes every wait a vmcnt(0).
-    if (n_active > 0) recon_round<true, MC>(a, s, f, ln, p, 0, km);
-#pragma unroll 1
-    for (int round = 1; round * ROUND_BLOCKS < n_active; round++) recon_round<false, MC>(a, s, f, ln, p, round, km);
-    PHASE_MARK(3);                              // IDCT rounds (the first waits for its coefficients)
-#if defined(H263MI_PROFILE_PHASES)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_MARK(4);                              // reference rows have arrived
-#endif
+    // (s_waitcnt vmcnt(8)) and leave the eight reference loads in flight under the row pass.
+    RoundState rs;
+    if (n_active > 0) recon_round_rows<true, MC>(a, s, f, ln, p, 0, km, rs);
+    PHASE_MARK(3);
     asm volatile("" : "+v"(ln));
-    wave_fence();                               // the residual strip is complete
-    ISA_MARK2(MC, "mc_", "intra_", "output_begin");
-    recon_phase_output<MC>(a, s, f, ln, p, km);
-    ISA_MARK2(MC, "mc_", "intra_", "output_end");
+    ISA_MARK2(MC, "mc_", "intra_", "predict_begin");
+    recon_phase_predict<MC>(a, s, f, ln, p, km);    // waits for the reference rows
+    ISA_MARK2(MC, "mc_", "intra_", "predict_end");
+    PHASE_MARK(4);
+    wave_fence();                                   // the prediction is in the strip
+    if (n_active > 0) recon_round_cols<MC>(s, ln, rs);
+#pragma unroll 1
+    for (int round = 1; round * ROUND_BLOCKS < n_active; round++) {
+        recon_round_rows<false, MC>(a, s, f, ln, p, round, km, rs);
+        recon_round_cols<MC>(s, ln, rs);
+    }
+    PHASE_MARK(5);
+    asm volatile("" : "+v"(ln));
+    wave_fence();                                   // the strip is complete
+    ISA_MARK2(MC, "mc_", "intra_", "store_begin");
+    recon_phase_store(a, s, ln, p, km);
+    ISA_MARK2(MC, "mc_", "intra_", "store_end");
 }
 
-// One wave's share of the reconstruction: the sub-tile(s) at `p` (RECON_HALVES of them, p.half counting up).
+// One wave's share of the reconstruction: the 8 macroblocks at `p`.
 __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int lane, WavePos p)
 {
     if (p.mby >= (int)a.L.mbh) return;
@@ -136,40 +160,36 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
     // `ln`: the lane index behind an opaque asm, re-derived per phase so that lane-only expressions are
     // recomputed where they are used instead of being kept in registers across the whole kernel
     int ln = lane;
-#pragma unroll 1
-    for (int h = 0; h < RECON_HALVES; h++, p.half++) {
-        asm volatile("" : "+v"(ln));
-        WaveMasks km;
-        km.valid = recon_valid_mask(a, p);
-        wave_fence();                               // the records are in LDS
-        const TaskInfo ti = recon_phase_mark(a, s, ln, p, km.valid, recon_block_limit(a, p));
-        const uint64_t act64 = __ballot(ti.active != 0), inter64 = __ballot(ti.inter != 0);
-        km.act = (uint32_t)act64;                   // bits 0..23
-        km.inter = (uint32_t)(inter64 >> WAVE_TASKS) & 0xffu;
-        recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index != 0) != 0);
-        recon_phase_compact(s, ln, ti, km.act);
-        wave_fence();                               // descriptors and chroma vectors are in LDS
-        ISA_MARK("mark_end");
-        PHASE_MARK(1);
-        // Two copies of the rest, chosen per wave (uniform): waves with a prediction to fetch, and waves without one --
-        // every wave of an I picture -- which issue no reference loads, compute no addresses for them and skip the
-        // interpolation (a third of the instructions of a dense intra wave).  Two copies rather than a switch inside one:
-        // the wait in front of the first IDCT round must know how many loads were issued behind the coefficient row.
-        if (a.has_ref && km.inter) recon_tail<true>(a, s, ln, p, km, t_prev_);
-        else recon_tail<false>(a, s, ln, p, km, t_prev_);
-        PHASE_MARK(5);
-    }
+    asm volatile("" : "+v"(ln));
+    WaveMasks km;
+    km.valid = recon_valid_mask(a, p);
+    wave_fence();                                   // the records are in LDS
+    const TaskInfo ti = recon_phase_mark(a, s, ln, p, km.valid, recon_block_limit(a, p));
+    const uint64_t act64 = __ballot(ti.active != 0), inter64 = __ballot(ti.inter != 0);
+    km.act = act64;                                 // bits 0..47
+    km.inter = (uint32_t)(inter64 >> MB_LANE0) & 0xffu;
+    recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index != 0) != 0);
+    recon_phase_compact(s, ln, ti, km.act);
+    wave_fence();                                   // descriptors and chroma vectors are in LDS
+    ISA_MARK("mark_end");
+    PHASE_MARK(1);
+    // Two copies of the rest, chosen per wave (uniform): waves with a prediction to fetch, and waves without one --
+    // every wave of an I picture -- which issue no reference loads, compute no addresses for them and skip the
+    // interpolation.  Two copies rather than a switch inside one: the wait in front of the first IDCT round must
+    // know how many loads were issued behind the coefficient row.
+    if (a.has_ref && km.inter) recon_tail<true>(a, s, ln, p, km, t_prev_);
+    else recon_tail<false>(a, s, ln, p, km, t_prev_);
+    PHASE_MARK(6);
 }
 
 __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 {
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
-    // grid.y = picture; grid.x walks the picture's (tile, macroblock row[, half]) list, RECON_WAVES entries per
-    // workgroup, in XCD-aware order (gridDim.x is a multiple of 8, so blockIdx.x & 7 names the XCD for every
-    // picture).  With RECON_HALVES == 2 a wave does both halves of its macroblock row one after the other.
+    // grid.y = picture; grid.x walks the picture's (tile, macroblock row) list, RECON_WAVES entries per workgroup, in
+    // XCD-aware order (gridDim.x is a multiple of 8, so blockIdx.x & 7 names the XCD for every picture).
     // No integer division on the device: the only one left, by tiles_x, is a multiply-high with a host-made reciprocal.
-    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_HALVES / RECON_WAVES;
+    constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_WAVES;
     const uint32_t upp = a.tiles_x * a.tiles_y * kUnitsPerTile;           // work items of one picture
     // a picture's list is dealt to a.bands XCDs in contiguous chunks, 8 / a.bands pictures side by side (see k_frame)
     const uint32_t bands = a.bands, xcd = blockIdx.x & 7;
@@ -177,13 +197,12 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     const uint32_t pic = blockIdx.y * (8 / bands) + xcd / bands;
     if (t >= chunk || g >= upp || pic >= a.n_pictures) return;
     const uint32_t tile = g / kUnitsPerTile;                               // power of two
-    const int tw = ((int)(g % kUnitsPerTile) * RECON_WAVES + wave) * RECON_HALVES;   // first sub-tile, 0..3
+    const int tw = (int)(g % kUnitsPerTile) * RECON_WAVES + wave;          // macroblock row of the tile
     const uint32_t tile_y = div_tiles_x(tile, a.tiles_x, a.inv_tiles_x), tile_x = tile - tile_y * a.tiles_x;
     WavePos p;
     p.pic = (int)pic;
     p.mbx0 = (int)tile_x * TILE_MBX;
-    p.mby = (int)tile_y * TILE_MBY + (tw >> 1);
-    p.half = tw & 1;
+    p.mby = (int)tile_y * TILE_MBY + tw;
     p.cbase = 0;
     recon_wave(a, waves[wave], lane, p);
 }
@@ -207,7 +226,7 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
     if (args.n_pictures > 65535 || args.tiles_x * args.tiles_y >= (1u << 20)) return hipErrorInvalidValue;
     ReconArgs a = args;
     a.inv_tiles_x = reciprocal_u32(args.tiles_x);
-    const uint32_t upp = args.tiles_x * args.tiles_y * (TILE_WAVES / RECON_HALVES / RECON_WAVES);
+    const uint32_t upp = args.tiles_x * args.tiles_y * (TILE_WAVES / RECON_WAVES);
     a.bands = frame_bands(args.n_pictures);
     const uint32_t chunk = (upp + a.bands - 1) / a.bands, side_by_side = 8 / a.bands;
     hipLaunchKernelGGL(k_recon, dim3(chunk * 8, (args.n_pictures + side_by_side - 1) / side_by_side), dim3(RECON_THREADS), 0,
@@ -319,8 +338,8 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 // k_frame: reconstruction of picture f and post-processing of picture f - 1 of every stream in ONE launch
 // (the frame-pipelined form of h263mi_batch_decode).  Both halves read the same frame set -- k_recon as its
 // reference picture, k_post as the picture to filter and convert -- and neither writes it, so they need no ordering
-// between them.  The work list of a picture is cut into GROUPS of 32 luma rows: the 4 * rtx reconstruction
-// sub-tiles of two macroblock rows, then the ptx post tiles over (almost) the same rows; the list is dealt to the 8
+// between them.  The work list of a picture is cut into GROUPS of 32 luma rows: the 2 * rtx reconstruction
+// waves of two macroblock rows (8 macroblocks each), then the ptx post tiles over (almost) the same rows; the list is dealt to the 8
 // XCDs in contiguous chunks as in the two kernels above.  Waves that read the same rows of the same picture thus run
 // at the same time on the same XCD: the planes are fetched from HBM once per frame instead of twice, and waves
 // bound by arithmetic and address work (reconstruction) share every CU with waves bound by stores (RGBA).
@@ -345,19 +364,22 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
     const uint32_t pic_y = blockIdx.y * (8 / bands) + side;
     if (t >= chunk || g >= upp || pic_y >= ra.n_pictures) return;
     const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group);
-    const uint32_t r = g - group * per_group;      // (post tiles in front of the reconstruction sub-tiles: no difference)
+    const uint32_t r = g - group * per_group;      // (post tiles in front of the reconstruction waves: no difference)
     const int pic = fg.flip ? (int)(ra.n_pictures - 1 - pic_y) : (int)pic_y;
     if (r < fg.recon_per_group) {
         WavePos p;
         p.pic = pic;
-        p.mbx0 = (int)(r >> 2) * TILE_MBX;
-        p.mby = (int)group * TILE_MBY + (int)((r >> 1) & 1);
-        p.half = (int)(r & 1);
+        p.mbx0 = (int)(r >> 1) * TILE_MBX;
+        p.mby = (int)group * TILE_MBY + (int)(r & 1);
         p.cbase = 0;
         recon_wave(ra, lds.r, lane, p);
     } else {
         if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
+#if defined(H263MI_EXP_PLAIN_RGBA)
+        post_wave<false>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic);
+#else
         post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic);
+#endif
     }
 }
 
@@ -365,7 +387,7 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
 {
     if (!rargs.n_pictures) return hipSuccess;
     if (rargs.n_pictures != pargs.n_pictures || rargs.n_pictures > 65535) return hipErrorInvalidValue;
-    static_assert(RECON_WAVES == 1 && RECON_HALVES == 1 && POST_WAVES == 1, "k_frame is written for single-wave workgroups");
+    static_assert(RECON_WAVES == 1 && TILE_WAVES == 2 && POST_WAVES == 1, "k_frame is written for single-wave workgroups");
     FrameGeom fg;
     fg.recon_per_group = rargs.tiles_x * TILE_WAVES;
     fg.post_per_group = pargs.tiles_x;

@@ -579,6 +579,9 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
                     px[k] = bt601_pack(gray + t.r, gray + t.g, gray + t.b);
                 }
                 const uint32_t off = off0 + (rr ? row_bytes : 0u);
+#if defined(H263MI_TIMING_NO_RGBA)
+                if (px[0] == 0x12345678u)                                  // TIMING EXPERIMENT ONLY: (almost) no RGBA store
+#endif
                 if (col_full) {
                     // one 16-byte store; the address is a multiple of 4 (of 16 when the width is a multiple of 4)
                     store16_align4<STREAM_RGBA>(rgba + off, px[0], px[1], px[2], px[3]);

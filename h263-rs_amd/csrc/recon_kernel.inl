@@ -5,34 +5,45 @@
 // 112-171), gather (gather.rs:140-204) and the three idct_channel calls (idct.rs:82-201)
 // issued at the tail of decode_next_picture (state.rs:432-458).
 //
-// Work unit = one WAVE = half a row of 8 macroblocks: wave "top" owns blocks Y0, Y1 and Cb of
-// the 8 macroblocks (a 128x8 luma strip + a 64x8 Cb strip), wave "bottom" owns Y2, Y3 and Cr.
-// That is 24 blocks and 3 x 64 eight-pixel row segments per wave; every luma row it stores is
-// one full 128-byte line.  A wave needs nothing from any other wave, so there is NO workgroup
-// barrier: hand-offs between lanes go through 5.8 KB of wave-private LDS and rely only on the
-// DS operations of one wave executing in order.  One wave is one workgroup (its LDS and
-// registers are released when it ends); the XCD-aware work order of kernels.hip keeps the four
-// waves of an 8x2-macroblock tile, and neighbouring tiles, on one L2.
+// Work unit = one WAVE = 8 whole macroblocks of one macroblock row: a 128x16 luma strip and the 64x8 strips of Cb
+// and Cr -- 48 block tasks, 3 072 reconstructed bytes.  A wave needs nothing from any other wave, so there is NO
+// workgroup barrier: hand-offs between lanes go through 5.9 KB of wave-private LDS and rely only on the DS
+// operations of one wave executing in order.  One wave is one workgroup (its LDS and registers are released when it
+// ends); the XCD-aware work order of kernels.hip keeps neighbouring waves on one L2.
+//
+// Round 3 redesign (profiles/README.md, r03): the kernel is bound by vector-instruction issue, so the wave was reshaped
+// to execute fewer instructions per reconstructed byte:
+//   * 8 whole macroblocks per wave instead of half of them: records, prologue and the mark phase are paid once for
+//     twice the pixels, and the IDCT rounds (8 blocks each) are filled from 48 tasks instead of 24;
+//   * the reconstruction is assembled in a BYTE strip in LDS: the prediction is written there first, the lanes of the
+//     column pass add their residuals to it in place (read-modify-write of the 8 bytes of their column), the store
+//     phase is a plain LDS -> HBM copy.  (Rounds 1-2 kept an i16 residual strip and added it to the prediction in
+//     the output phase: the add / saturate / pack ran for every segment of the wave, coded or not.)
+//   * a lane predicts VERTICALLY ADJACENT rows of one block (4 luma rows, 2 chroma rows): 5 + 3 reference rows
+//     are loaded instead of 8 + 4, the byte alignment and the horizontal half of the half-pel filter are computed
+//     once per loaded row and shared by the two output rows that use it, and vector, flags and addresses are per
+//     lane, not per row.
 //
 // Wave timeline:
 //   records  : 8 records (256 B) -> LDS
-//   mark     : lane t < 24 = block task t: decides whether the block goes through the IDCT (coded & !kill, or
+//   mark     : lane t < 48 = block task t: decides whether the block goes through the IDCT (coded & !kill, or
 //              uncoded intra with non-zero DC) and builds its 8-byte DESCRIPTOR (where its coefficients are,
-//              quantiser, INTRADC level, intra flag, task number); lanes 24..31 = the 8 macroblocks: chroma vector
+//              quantiser, INTRADC level, intra flag, task number); lanes 48..55 = the 8 macroblocks: chroma vector
 //              (packed 16-bit arithmetic) and the inter flag.  The wave-wide masks are ballots (scalar registers);
-//              the descriptors of the active tasks are compacted in LDS -- every later phase reads a descriptor
-//              instead of walking list -> record -> cbp -> popcount -> coeff_index again
-//   fetch    : ALL global loads are issued now, before any arithmetic: the reference rows of
-//              the lane's three segments (one dword-aligned 12-byte load per row; rows nobody
-//              needs read offset 0; picture-edge segments load the window that holds all their
-//              clamped taps) and the coefficient row of the first IDCT round
-//   idct     : rounds of 8 blocks, 8 lanes per block, lane = one coefficient row: dequant (packed i16),
-//              row pass T = C x B -> LDS; then lane = one pixel column: column of T (the
-//              LDS transposition), column pass, rounding -> residual strip (i16) in LDS; both
+//              the descriptors of the active tasks are compacted in LDS
+//   fetch    : ALL global loads are issued now, before any arithmetic: the coefficient row of the first IDCT round,
+//              then the reference rows of the lane's luma block (5) and chroma block (3): one dword-aligned 12-byte
+//              load per row; rows nobody needs read offset 0; picture-edge lanes load the window that holds all
+//              their clamped taps
+//   rows 0   : first IDCT round, row pass (lane = one coefficient row): dequant (packed i16), T = C x B -> LDS.  Runs
+//              under the reference loads.
+//   predict  : lane = 4 luma rows + 2 chroma rows of 8 pixels: one branch-free half-pel form on packed bytes
+//              -> byte strip in LDS (zeros where nothing is predicted)
+//   cols 0.. : column pass (lane = one pixel column): column of T (the LDS transposition), rounding, residual added
+//              to the strip in place with the final clamp; then the remaining rounds, row + column pass each; both
 //              passes stop at the last non-zero coefficient column / row of the round; the block classes
 //              (rle.rs:138-170) come out of two ballots
-//   output   : lane = 8 horizontal pixels: one branch-free half-pel form on packed bytes, + residual
-//              row (packed i16 add, saturating pack to u8), one 8-byte store
+//   store    : strip -> frame, 8 bytes per lane and row
 //
 // Bit-exactness rules: f32 multiply and add are separately rounded
 // (translation unit built with -ffp-contract=off), accumulation order over the
@@ -44,25 +55,20 @@
 namespace h263mi {
 
 #ifndef H263MI_RECON_WAVES
-#define H263MI_RECON_WAVES 1       // measured: 1 -> 0.237 ms, 2 -> 0.241 ms, 4 -> 0.248 ms per launch (64 x 1080p P pictures)
+#define H263MI_RECON_WAVES 1       // measured in round 1: 1 -> 0.237 ms, 2 -> 0.241 ms, 4 -> 0.248 ms per launch
 #endif
-constexpr int RECON_WAVES = H263MI_RECON_WAVES;      // waves per workgroup (they are independent: 1, 2 or 4)
+constexpr int RECON_WAVES = H263MI_RECON_WAVES;      // waves per workgroup of k_recon (they are independent: 1 or 2)
 constexpr int RECON_THREADS = RECON_WAVES * 64;
-constexpr int TILE_WAVES = 4;                        // sub-tiles (macroblock row x half) per 8x2-macroblock tile
-#ifndef H263MI_RECON_HALVES
-#define H263MI_RECON_HALVES 1
-#endif
-constexpr int RECON_HALVES = H263MI_RECON_HALVES;    // sub-tiles a wave processes back to back: 1, or 2 = both halves of its row
-constexpr int TILE_MBX = 8, TILE_MBY = 2;      // macroblocks per workgroup
-constexpr int WAVE_TASKS = 24;                 // 16 luma + 8 chroma blocks per wave
+constexpr int TILE_MBX = 8, TILE_MBY = 2;      // macroblocks per tile (the unit the frame-pipelined work list is grouped by)
+constexpr int TILE_WAVES = TILE_MBY;           // waves per tile: one per macroblock row
+constexpr int WAVE_TASKS = 48;                 // 32 luma + 8 Cb + 8 Cr blocks per wave
+constexpr int LUMA_TASKS = 32;
 constexpr int ROUND_BLOCKS = 8;                // blocks per IDCT round (8 lanes each)
 constexpr int TBUF_ROW = 8;                    // floats per row of a block slot: T[r][0..7], written as two 16-byte stores
 constexpr int TBUF_STRIDE = 8 * TBUF_ROW + 8;  // 72 floats per slot: 8 pad floats make the column reads bank-conflict free
-#if defined(H263MI_TIMING_RES_STRIDE)
-constexpr int RES_STRIDE = H263MI_TIMING_RES_STRIDE;   // TIMING EXPERIMENT ONLY (rows overlap, results wrong): a smaller LDS footprint
-#else
-constexpr int RES_STRIDE = 192;                // residual strip row: 128 luma + 64 chroma columns
-#endif
+constexpr int PIX_STRIDE = 128;                // bytes per row of the reconstruction strip
+constexpr int PIX_CHROMA = 16 * PIX_STRIDE;    // rows 0..15: luma; rows 16..23: Cb in columns 0..63, Cr in 64..127
+constexpr int MB_LANE0 = WAVE_TASKS;           // lanes 48..55 of the mark phase are the 8 macroblocks
 
 struct ReconWave {
     uint32_t rec[TILE_MBX][8];                 // the 8 records as dwords: [0] mb_type | quant << 8 | cbp << 16 | kill << 24,
@@ -70,8 +76,9 @@ struct ReconWave {
     uint32_t mvc[TILE_MBX];                    // chroma vector per macroblock, x | y << 16 (gather.rs:182)
     uint32_t desc[WAVE_TASKS][2];              // descriptors of the active tasks, compacted (see TaskInfo)
     float    tbuf[ROUND_BLOCKS * TBUF_STRIDE]; // row pass results T[r][i] of the round's 8 blocks
-    int16_t  res[7 * RES_STRIDE + 192];        // residual strip: 8 rows x (128 luma | 64 chroma) columns
+    uint8_t  pix[24 * PIX_STRIDE];             // the reconstruction strip: prediction, then + residuals, then stored
 };
+static_assert(sizeof(ReconWave) <= 6064, "27 waves per CU need <= 6 068 bytes of LDS per wave (profiles/r03_b_ab_lds_pad.txt)");
 static_assert(sizeof(MbRecord) == 32 && offsetof(MbRecord, mv) == 4 && offsetof(MbRecord, intradc) == 20 &&
               offsetof(MbRecord, coeff_index) == 28, "record words used by the mark phase");
 
@@ -94,13 +101,13 @@ H263_HD int      desc_task(uint32_t d1) { return (int)(d1 >> 20); }
 // (tests/sim) runs the lanes one after the other and ORs the lanes' bits together.
 struct WaveMasks {
     uint32_t valid;            // bit m: macroblock m lies inside the picture
-    uint32_t act;              // bit t: block task t goes through the IDCT
+    uint64_t act;              // bit t: block task t goes through the IDCT
     uint32_t inter;            // bit m: macroblock m is inside the picture and inter coded
 };
 
-// position of a wave's work: which picture, which row of macroblocks, which half
+// position of a wave's work: which picture, which 8 macroblocks
 struct WavePos {
-    int pic, mbx0, mby, half;
+    int pic, mbx0, mby;
     uint64_t cbase;            // coeff_base[pic] (0 without a base array), fetched once per wave
 };
 
@@ -112,12 +119,36 @@ H263_HD int popc32(uint32_t v)
     return __builtin_popcount(v);
 #endif
 }
+H263_HD int popc64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
+// set bits of `mask` below bit `lane` (v_mbcnt_lo / v_mbcnt_hi on the device)
+H263_DEV int popc_below(uint64_t mask, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#else
+    return __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+#endif
+}
 
-H263_HD int recon_n_active(const WaveMasks &k) { return popc32(k.act); }
+H263_HD int recon_n_active(const WaveMasks &k) { return popc64(k.act); }
 
-// block task t of a wave -> (macroblock 0..7, block 0..5)
-H263_HD int task_mb(int t) { return t < 16 ? (t >> 1) : (t - 16); }
-H263_HD int task_blk(int t, int half) { return t < 16 ? (half * 2 + (t & 1)) : (4 + half); }
+// Block task t of a wave: t < 32 luma, block row t >> 4 (the upper / lower blocks of the macroblocks), block column
+// t & 15; then the 8 Cb blocks, then the 8 Cr blocks.
+H263_HD int task_mb(int t) { return t < LUMA_TASKS ? ((t >> 1) & 7) : (t & 7); }
+H263_HD int task_blk(int t) { return t < LUMA_TASKS ? (((t >> 4) << 1) | (t & 1)) : 4 + ((t >> 3) & 1); }
+// where the block's 8x8 pixels start in the reconstruction strip
+H263_HD int task_pix_origin(int t)
+{
+    return t < LUMA_TASKS ? (t >> 4) * 8 * PIX_STRIDE + (t & 15) * 8 : PIX_CHROMA + ((t >> 3) & 1) * 64 + (t & 7) * 8;
+}
 
 // ---- packed helpers (device: single instructions; host build: plain C for tests/sim) ----------
 // v_lerp_u8: per byte (a + b + (c & 1)) >> 1
@@ -133,22 +164,6 @@ H263_DEV uint32_t lerp_u8x4(uint32_t a, uint32_t b, uint32_t c)
     }
     return out;
 #endif
-}
-
-// per-byte (a + b + 1) >> 1
-H263_DEV uint32_t avg2_u8x4(uint32_t a, uint32_t b) { return lerp_u8x4(a, b, 0x01010101u); }
-
-// per-byte (a + b + c + d + 2) >> 2, without leaving the packed bytes.  With a + b = 2*h1 + l1 and
-// c + d = 2*h2 + l2 the sum is 2*(h1 + h2) + (l1 + l2 + 2), so the result is
-// (h1 + h2 + 1 + (l1 & l2)) >> 1: the rounding average of the two floor averages, plus one exactly
-// where both low bits are set and h1 + h2 is even (an odd h1 + h2 absorbs the extra one).
-// avg4(a, a, b, b) == avg2(a, b) and avg4(a, a, a, a) == a, which is what lets the output phase use this
-// one form for all four half-pel cases.
-H263_DEV uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    const uint32_t h1 = lerp_u8x4(a, b, 0u), h2 = lerp_u8x4(c, d, 0u);
-    const uint32_t carry = (a ^ b) & (c ^ d) & ~(h1 ^ h2) & 0x01010101u;
-    return lerp_u8x4(h1, h2, 0x01010101u) + carry;
 }
 
 // clamp(v, lo, hi) for lo <= hi as one v_med3_i32
@@ -190,29 +205,6 @@ H263_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
     return __builtin_amdgcn_alignbyte(hi, lo, sh);              // v_alignbyte_b32
 #else
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh));
-#endif
-}
-
-// four prediction bytes + four i16 residuals (two dwords) -> four clipped bytes
-// (clipped_idct + mocomp_pixel).clamp(0, 255)  idct.rs:127-130, 191-194
-H263_DEV uint32_t add_clip_u8x4(uint32_t pred, uint32_t r01, uint32_t r23)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t p01 = __builtin_amdgcn_perm(0u, pred, 0x0c010c00u);       // (p0, p1) as i16
-    const uint32_t p23 = __builtin_amdgcn_perm(0u, pred, 0x0c030c02u);       // (p2, p3)
-    // v_sat_pk_u8_i16: both halves saturated to 0..255 and packed into bits 15:0 (what it leaves in bits 31:16 is
-    // not relied upon: the permute below picks bytes 0 and 1 of each)
-    const uint32_t b01 = sat_pk_u8_i16(pk_add_u16(p01, r01)), b23 = sat_pk_u8_i16(pk_add_u16(p23, r23));
-    return __builtin_amdgcn_perm(b23, b01, 0x05040100u);
-#else
-    uint32_t out = 0;
-    const uint32_t r[2] = {r01, r23};
-    for (int k = 0; k < 4; k++) {
-        int rr = (int)(int16_t)(r[k >> 1] >> ((k & 1) * 16));
-        int p = (int)((pred >> (8 * k)) & 0xff);
-        out |= (uint32_t)clampi(p + rr, 0, 255) << (8 * k);
-    }
-    return out;
 #endif
 }
 
@@ -314,16 +306,6 @@ H263_HD int rows_from_mask(uint32_t row_mask)       // bit r: some block has a n
     return n;
 }
 
-// median of three = clamp(v, lo, hi) for lo <= hi (one v_med3_f32; no NaNs can occur here)
-H263_DEV float clampf(float v, float lo, float hi)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_fmed3f(v, lo, hi);
-#else
-    return v < lo ? lo : (v > hi ? hi : v);
-#endif
-}
-
 // rle.rs:130-133 for two LEVELs at once, as they arrive (a pair of int16 in one dword):
 // sign(L) * (q*(2|L|+1) - (q even)) = L*2q + sign(L)*(q - parity), clamped to [-2048, 2047]; 0 stays 0.
 // Packed 16-bit integer arithmetic; the multiply-add saturates to the i16 range (the reference's i16 product would
@@ -355,7 +337,7 @@ H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qm
 // ---- phase 0: records -> LDS -------------------------------------------------------
 H263_DEV uint32_t recon_valid_mask(const ReconArgs &a, const WavePos &p)
 {
-    const int n = (int)a.L.mbw - p.mbx0;                        // macroblocks of the tile inside the picture
+    const int n = (int)a.L.mbw - p.mbx0;                        // macroblocks of the wave inside the picture
     return (p.mby < (int)a.L.mbh && n > 0) ? (n >= TILE_MBX ? 0xffu : (1u << n) - 1u) : 0u;
 }
 
@@ -380,7 +362,11 @@ H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const
         const int mbx = p.mbx0 + m;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (mbx < (int)a.L.mbw && p.mby < (int)a.L.mbh) {
+#if defined(H263MI_TIMING_REC_WRAP)
+            const MbRecord *r = a.mbs + (((size_t)p.mby * a.L.mbw + mbx) & 2047u);   // TIMING EXPERIMENT ONLY: 64 KB of records
+#else
             const MbRecord *r = a.mbs + (size_t)p.pic * a.mbs_per_picture + (size_t)p.mby * a.L.mbw + mbx;
+#endif
             v = reinterpret_cast<const uint4 *>(r)[part];
         }
         reinterpret_cast<uint4 *>(&s.rec[m][0])[part] = v;
@@ -389,19 +375,19 @@ H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const
 
 // ---- phase 1: which blocks need the IDCT, their descriptors; chroma vectors -------------------------------
 // Straight-line and branch-free: every lane reads the eight words of "its" record (four two-dword LDS reads from one
-// address register), the decisions are plain arithmetic.  Lanes 0..23 are block task `lane`, lanes 24..31 macroblock
-// lane - 24; the other lanes compute along and are ignored.
-H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, const WavePos &p, uint32_t valid_mask,
+// address register), the decisions are plain arithmetic.  Lanes 0..47 are block task `lane`, lanes 48..55 macroblock
+// lane - 48; the other lanes compute along and are ignored.
+H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, const WavePos &, uint32_t valid_mask,
                                    uint32_t block_limit)
 {
     // Decisions are 0 / 1 integers combined with shifts, ands and ors -- the 2-cycle VALU instructions; written with
     // bool / ?: the same logic compiles to compares and selects at twice the price each (profiles/README.md).
     const uint32_t ln = (uint32_t)lane;
-    const uint32_t is_task = (ln - WAVE_TASKS) >> 31;                        // lane < 24
-    const uint32_t is_mb = ((ln - WAVE_TASKS) < (uint32_t)TILE_MBX) ? 1u : 0u;
-    const uint32_t luma_task = (ln - 16u) >> 31;                              // lane < 16
-    const uint32_t m = (ln >> luma_task) & 7u;                                // lane >> 1 for luma tasks, lane & 7 else
-    const uint32_t blk = luma_task ? (uint32_t)(p.half * 2) + (ln & 1u) : (uint32_t)(4 + p.half);
+    const uint32_t is_task = (ln - (uint32_t)WAVE_TASKS) >> 31;                // lane < 48
+    const uint32_t is_mb = ((ln - (uint32_t)MB_LANE0) < (uint32_t)TILE_MBX) ? 1u : 0u;
+    const uint32_t luma_task = (ln - (uint32_t)LUMA_TASKS) >> 31;              // lane < 32
+    const uint32_t m = (ln >> luma_task) & 7u;                                 // lane >> 1 for luma tasks, lane & 7 else
+    const uint32_t blk = luma_task ? (((ln >> 4) << 1) | (ln & 1u)) : 4u + ((ln >> 3) & 1u);
     const uint32_t *r = s.rec[m];
     const uint32_t w0 = r[0], w7 = r[7], w5 = r[5], w6 = r[6], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4];
 
@@ -445,10 +431,10 @@ H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, co
 }
 
 // ---- phase 2: compact the descriptors of the active tasks ----------------------------------------------
-H263_DEV void recon_phase_compact(ReconWave &s, int lane, const TaskInfo &t, uint32_t act_mask)
+H263_DEV void recon_phase_compact(ReconWave &s, int lane, const TaskInfo &t, uint64_t act_mask)
 {
     if (!t.active) return;
-    uint32_t *d = s.desc[popc32(act_mask & ((1u << lane) - 1u))];
+    uint32_t *d = s.desc[popc_below(act_mask, lane)];
     d[0] = t.d0;
     d[1] = t.d1;
 }
@@ -467,54 +453,49 @@ H263_DEV void recon_report(const ReconArgs &a, int lane, bool inter_without_refe
 }
 
 // ---- phase 3: issue every global load of the wave ------------------------------------------
-// One 8-pixel row segment of the lane: its motion vector and the raw reference bytes (12 per
-// tap row: 9 are needed at most; a dwordx3 keeps it to one load per row).
+// A lane predicts two pieces of the strip: rows 4g .. 4g+3 of one luma block column (g = lane >> 4, column lane & 15)
+// and rows 2g' .. 2g'+1 of one chroma block (plane lane >> 5, g' = (lane >> 3) & 3, macroblock lane & 7).  All rows
+// of a piece lie in ONE block: one vector, one set of flags, and output row j needs reference rows v + j and
+// v + j + (mvy & 1) -- 5 (3) consecutive rows for 4 (2) output rows.
 enum : uint8_t { SEG_INTER = 1, SEG_BORDER = 2 };
-struct SegFetch {
-    uint32_t r0[3], r1[3];     // reference rows v and v + 1, bytes u .. u+11 (r1 only where mvy is odd)
-};
+constexpr int LUMA_ROWS = 4, CHROMA_ROWS = 2;
 struct WaveFetch {
-    SegFetch seg[3];           // [0], [1]: luma rows (lane>>4) and 4 + (lane>>4); [2]: chroma row lane>>3
-    uint32_t mvw[2];           // [0] luma (shared by segments 0 and 1), [1] chroma: mvx | mvy << 16;
-                               // (0, 0) when the macroblock takes no prediction
-    uint32_t flags;            // two bits per vector: SEG_INTER: motion compensated (else prediction = 0);
-                               // SEG_BORDER: some tap falls outside the picture, redone with clamping
-    uint32_t d0, d1;           // descriptor of the lane's block in the first IDCT round
-    uint4    coef0;            // ... and its coefficient row
+    uint32_t ly[LUMA_ROWS + 1][3];     // luma: reference rows v .. v+4, bytes ua .. ua+11 (the last one only where mvy is odd)
+    uint32_t ch[CHROMA_ROWS + 1][3];   // chroma: rows v .. v+2
+    uint32_t mvw[2];                   // [0] luma, [1] chroma: mvx | mvy << 16; (0, 0) when the macroblock takes no prediction
+    uint32_t flags;                    // bits 0..1 luma, 2..3 chroma: SEG_INTER: motion compensated (else prediction = 0);
+                                       // SEG_BORDER: some tap falls outside the picture, redone with clamping
+    uint32_t d0, d1;                   // descriptor of the lane's block in the first IDCT round
+    uint4    coef0;                    // ... and its coefficient row
 };
 
-// segment k of a lane -> geometry.  Segments 0 and 1 are the same luma column, four rows apart.
-struct SegGeo {
-    int m, blk, task, px, py, pitch, pw, ph, resoff;   // resoff: index into the residual strip
-    uint32_t plane_off;                                // uniform per (wave, k)
-    bool luma;
+// piece k of a lane (0 luma, 1 chroma) -> geometry
+struct PieceGeo {
+    int m, blk, px, py, pitch, pw, ph, pixoff;
+    uint32_t plane_off;                // luma: 0; chroma: the lane's plane (lanes 0..31 Cb, 32..63 Cr)
 };
 
-H263_DEV SegGeo seg_geometry(const ReconArgs &a, int lane, int k, const WavePos &p)
+H263_DEV PieceGeo piece_geometry(const ReconArgs &a, int lane, int k, const WavePos &p)
 {
-    SegGeo g;
-    if (k < 2) {
-        const int row = (lane >> 4) + 4 * k, sx = lane & 15;      // 16 lanes = one 128-byte luma line
-        g.luma = true;
+    PieceGeo g;
+    if (k == 0) {
+        const int sx = lane & 15, rg = lane >> 4;                 // 16 lanes = one 128-byte luma line
         g.m = sx >> 1;
-        g.blk = p.half * 2 + (sx & 1);
-        g.task = sx;
+        g.blk = ((rg >> 1) << 1) | (sx & 1);
         g.px = p.mbx0 * 16 + sx * 8;
-        g.py = p.mby * 16 + p.half * 8 + row;
+        g.py = p.mby * 16 + rg * LUMA_ROWS;
         g.pitch = (int)a.L.pitch_y; g.pw = (int)a.L.width; g.ph = (int)a.L.height;
         g.plane_off = 0;
-        g.resoff = row * RES_STRIDE + sx * 8;
+        g.pixoff = rg * LUMA_ROWS * PIX_STRIDE + sx * 8;
     } else {
-        const int row = lane >> 3, sx = lane & 7;
-        g.luma = false;
+        const int plane = lane >> 5, sx = lane & 7, rg = (lane >> 3) & 3;
         g.m = sx;
-        g.blk = 4 + p.half;
-        g.task = 16 + sx;
+        g.blk = 4 + plane;
         g.px = p.mbx0 * 8 + sx * 8;
-        g.py = p.mby * 8 + row;
+        g.py = p.mby * 8 + rg * CHROMA_ROWS;
         g.pitch = (int)a.L.pitch_c; g.pw = (int)a.L.cwidth; g.ph = (int)a.L.cheight;
-        g.plane_off = p.half ? a.L.off_cr : a.L.off_cb;
-        g.resoff = row * RES_STRIDE + 128 + sx * 8;
+        g.plane_off = plane ? a.L.off_cr : a.L.off_cb;
+        g.pixoff = PIX_CHROMA + rg * CHROMA_ROWS * PIX_STRIDE + plane * 64 + sx * 8;
     }
     return g;
 }
@@ -534,11 +515,9 @@ H263_DEV void load12(const uint8_t *p, uint32_t out[3])
 }
 
 // Border path (gather.rs:24-25: every tap is clamped to the picture on its own).  Clamping only ever repeats the
-// first or the last pixel of the row, so all nine taps of a segment lie in one 12-byte window of that row:
-// column 0.. when the segment starts left of the picture, else the last aligned window that still reaches the
-// final pixel.  The fetch phase loads that window; the output phase picks tap k = window[clamp(u + k) - ub].
-// No memory access, no wait: this path used to be a byte-load loop and cost 15 % of the kernel on 1080p
-// P pictures, where one wave in twelve has a macroblock at the picture edge.
+// first or the last pixel of the row, so all nine taps of a row lie in one 12-byte window of that row:
+// column 0.. when the piece starts left of the picture, else the last aligned window that still reaches the
+// final pixel.  The fetch phase loads that window; the predict phase picks tap k = window[clamp(u + k) - ub].
 H263_HD int border_window(int u, int pw)
 {
     const int last = (pw - 9) & ~3;                    // smallest multiple of 4 that is >= pw - 12
@@ -567,21 +546,37 @@ H263_DEV void gather_row_clamped(uint32_t w[3], int u, int ub, int pw)
     w[0] = o0; w[1] = o1; w[2] = o2;
 }
 
+// 16 bytes of read-once data (coefficients)
+H263_DEV uint4 load16_stream(const uint8_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(H263MI_EXP_NT_COEFS)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+
 // coefficient row `r` of the block descriptor d0 describes (any mapped address when there is none)
 H263_DEV const uint8_t *coeff_row_address(const ReconArgs &a, const WavePos &p, uint32_t d0, bool wanted, int r)
 {
     const uint8_t *pic = reinterpret_cast<const uint8_t *>(a.coeffs) + p.cbase * 128u;      // uniform
+#if defined(H263MI_TIMING_COEF_WRAP)
+    // TIMING EXPERIMENT ONLY (results wrong): every coefficient block comes out of one 64 KB region (cache resident)
+    return (wanted && d0 != NO_COEFFS) ? reinterpret_cast<const uint8_t *>(a.coeffs) + (d0 & 0xff80u) + (uint32_t)r * 16u
+                                       : reinterpret_cast<const uint8_t *>(a.mbs);
+#endif
     return (wanted && d0 != NO_COEFFS) ? pic + d0 + (uint32_t)r * 16u : reinterpret_cast<const uint8_t *>(a.mbs);
 }
 
-// The loads are issued unconditionally and in a fixed order -- coefficient row first, then two
-// 12-byte reference rows per segment -- so that the wait in front of the row pass can leave the six
-// reference loads in flight (s_waitcnt vmcnt(6)): the IDCT of this wave overlaps its own motion
-// compensation reads.  A lane whose macroblock takes no prediction behaves like a zero vector (its
-// bytes are dropped in the output phase); lanes whose taps leave the picture are fixed up there too.
-// Every address is a wave-uniform plane base plus a 32-bit lane offset.
+// The loads are issued unconditionally and in a fixed order -- coefficient row first, then the 5 + 3 reference rows --
+// so that the wait in front of the first row pass can leave the eight reference loads in flight (s_waitcnt vmcnt(8)):
+// the first IDCT round overlaps the wave's own motion compensation reads.  A lane whose macroblock takes no prediction
+// reads offset 0 (its bytes are dropped in the predict phase); lanes whose taps leave the picture are fixed up there
+// too.  Every address is a wave-uniform frame base plus a 32-bit lane offset.
 // MC = false: no macroblock of the wave takes a prediction (every wave of an I picture): only the coefficient row is
-// requested -- no reference rows, no addresses for them -- and the output phase starts from zeros.
+// requested -- no reference rows, no addresses for them -- and the predict phase writes zeros.
 template <bool MC = true>
 H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
 {
@@ -590,7 +585,7 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
         const int slot = lane >> 3, r = lane & 7;
         f.d0 = s.desc[slot][0];                                // (garbage beyond the active tasks: never used)
         f.d1 = s.desc[slot][1];
-        f.coef0 = *reinterpret_cast<const uint4 *>(coeff_row_address(a, p, f.d0, slot < recon_n_active(km), r));
+        f.coef0 = load16_stream(coeff_row_address(a, p, f.d0, slot < recon_n_active(km), r));
     }
     if (!MC) {
         f.flags = f.mvw[0] = f.mvw[1] = 0;
@@ -601,33 +596,37 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
     const uint32_t mc_mask = a.has_ref ? km.inter : 0u;
     f.flags = 0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        SegFetch &sf = f.seg[k];
-        const SegGeo g = seg_geometry(a, lane, k, p);
-        const bool mc = (mc_mask >> g.m) & 1;
-        uint32_t mvw = g.luma ? s.rec[g.m][1 + g.blk] : s.mvc[g.m];     // (mvx, mvy) as one LDS word
-        mvw = mc ? mvw : 0u;
+    for (int k = 0; k < 2; k++) {
+        const PieceGeo g = piece_geometry(a, lane, k, p);
+        const uint32_t mc = (mc_mask >> g.m) & 1u;
+        uint32_t mvw = k == 0 ? s.rec[g.m][1 + g.blk] : s.mvc[g.m];     // (mvx, mvy) as one LDS word
+        mvw &= 0u - mc;
+#if defined(H263MI_TIMING_ZERO_MV)
+        mvw = 0;                                                     // TIMING EXPERIMENT ONLY (results wrong): every vector (0, 0)
+#elif defined(H263MI_TIMING_SMALL_MV)
+        mvw &= 0x00030003u;                                          // TIMING EXPERIMENT ONLY: vectors 0..1.5 pixels, half-pel phases kept
+#endif
         const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int16_t)(mvw >> 16);
         // HalfPel::into_lerp_parameters (types.rs:721-729): floor(mv / 2), odd -> interpolate
         const int ix = mvx & 1, iy = mvy & 1;
         const int u = g.px + (mvx >> 1), v = g.py + (mvy >> 1);
         const bool inside = u >= 0 && u <= g.pw - 8 - ix;
-        if (k != 1) {
-            f.mvw[k >> 1] = mvw;
-            f.flags |= (uint32_t)((mc ? SEG_INTER : 0) | ((mc && !inside) ? SEG_BORDER : 0)) << (k & 2);
-        }
+        f.mvw[k] = mvw;
+        f.flags |= (mc | ((mc && !inside) ? (uint32_t)SEG_BORDER : 0u)) << (2 * k);
         // inside lanes read at u (the 12-byte load may run past the row end: next row or padding); border lanes
-        // read the window that holds all their clamped taps (border_window)
+        // read the window that holds all their clamped taps (border_window).  The loads themselves are dword aligned
+        // (bytes (uc & ~3) .. +11 still cover the 9 taps); the predict phase shifts the window by uc & 3.
         const uint32_t uc = (uint32_t)(inside ? u : border_window(u, g.pw));
-        const uint32_t row0 = (uint32_t)med3i(v, 0, g.ph - 1), row1 = (uint32_t)med3i(v + 1, 0, g.ph - 1);
-        // rows nobody needs (no prediction; integer vertical vector) read offset 0: one cache line for the
-        // whole wave instead of one per lane -- the address path is as loaded as the arithmetic here
-        // The loads themselves are dword aligned (bytes (uc & ~3) .. +11 still cover the 9 taps); the output
-        // phase shifts the window by uc & 3.  Misaligned dwordx3 loads measured ~5 % slower overall.
-        const uint8_t *plane = ref + g.plane_off;
-        const uint32_t ua = uc & ~3u;
-        load12(plane + (mc ? mad24(row0, (uint32_t)g.pitch, ua) : 0u), sf.r0);
-        load12(plane + (iy ? mad24(row1, (uint32_t)g.pitch, ua) : 0u), sf.r1);
+        const uint32_t ua = g.plane_off + (uc & ~3u);
+        const int n_rows = k == 0 ? LUMA_ROWS : CHROMA_ROWS;
+#pragma unroll
+        for (int j = 0; j <= n_rows; j++) {
+            // rows nobody needs (no prediction; the extra row of an integer vertical vector) read offset 0: one cache
+            // line for the whole wave instead of one per lane
+            const bool need = mc && (j < n_rows || iy);
+            const uint32_t row = (uint32_t)med3i(v + j, 0, g.ph - 1);
+            load12(ref + (need ? mad24(row, (uint32_t)g.pitch, ua) : 0u), k == 0 ? f.ly[j] : f.ch[j]);
+        }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     // keep the per-lane state as three vector registers: without this the compiler carries the lane
@@ -656,7 +655,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
         d0 = s.desc[k % WAVE_TASKS][0];
         ri.d1 = s.desc[k % WAVE_TASKS][1];
         // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r)
-        raw = *reinterpret_cast<const uint4 *>(coeff_row_address(a, p, d0, ri.active, r));
+        raw = load16_stream(coeff_row_address(a, p, d0, ri.active, r));
     }
     const bool has = ri.active && d0 != NO_COEFFS;
     ri.w[0] = has ? raw.x : 0u; ri.w[1] = has ? raw.y : 0u; ri.w[2] = has ? raw.z : 0u; ri.w[3] = has ? raw.w : 0u;
@@ -721,7 +720,7 @@ H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
     float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW + 4], T[2], T[3]);
 }
 
-// ---- phase 4b: column pass, rounding, residual strip -------------------------------------
+// ---- phase 4b: column pass, rounding, residual into the strip -----------------------------
 // rows_any / cols_any: bit slot*8 + r set when coefficient row r of the slot's block holds a non-zero value /
 // one in a column x > 0 (ballots of RowClass on the device).  A block is Horiz when no row r > 0 holds anything,
 // Vert when no row holds anything beyond column 0, Dc (or Zero) when both (rle.rs:138-171).
@@ -757,18 +756,22 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
 #pragma unroll
         for (int jp = 0; jp < 4; jp++) O[jp] = O[jp] * scale + shift;
     }
-    int16_t *base = &s.res[(t < 16 ? t * 8 : 128 + (t - 16) * 8) + i];
+    // The lane's column of the block in the strip already holds the prediction (or zeros): add the residual in place.
+    //   r = ((v / 4.0 + signum(v) * 0.5) as i16).clamp(-256, 255)   idct.rs:189-190: signum(+-0) only decides the sign
+    //       of a half that truncation removes, so copysign is enough; `as i16` truncates toward zero
+    //   pixel = (r + prediction).clamp(0, 255)                      idct.rs:127-130, 191-194
+    // The clamp of r to [-256, 255] is implied by the final one (the prediction is 0..255: any r >= 255 ends at 255,
+    // any r <= -255 at 0), and |v| stays far below 2^31, so the conversion cannot saturate.
+    uint8_t *base = &s.pix[task_pix_origin(t) + i];
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) {
         const f32x2 o = O[jp];
         const f32x2 q4 = o * splat2(0.25f);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            // ((v / 4.0 + signum(v) * 0.5) as i16).clamp(-256, 255)  idct.rs:189-190.  signum(+-0) only
-            // decides the sign of a half that truncation removes, so copysign is enough; truncation is
-            // monotone, so clamping the float to [-256.0, 255.5] first gives the same integer.
             const float v = q4[h] + __builtin_copysignf(0.5f, o[h]);
-            base[(jp * 2 + h) * RES_STRIDE] = (int16_t)(int)clampf(v, -256.0f, 255.5f);
+            uint8_t *px = base + (jp * 2 + h) * PIX_STRIDE;
+            *px = (uint8_t)med3i((int)v + (int)*px, 0, 255);
         }
     }
 }
@@ -780,69 +783,107 @@ H263_DEV bool recon_block_is_special(const RowIn &ri, int lane, uint64_t rows_an
     return ri.active && ((((uint32_t)(rows_any >> (8 * slot)) & 0xfeu) == 0) || (((uint32_t)(cols_any >> (8 * slot)) & 0xffu) == 0));
 }
 
-// ---- phase 5: interpolation + residual + clip + store ------------------------------------
+// ---- phase 5: prediction -> strip -----------------------------------------------------------
+// What a reference row contributes to the half-pel filter, per 4 output pixels: with a = the taps at u.., s = the taps
+// at u + (mvx & 1)..:  H = (a + s) >> 1 per byte, X = a ^ s (its low bit is the bit the floor average dropped).
+struct RowTerms {
+    uint32_t h[2], x[2];       // [0] pixels 0..3, [1] pixels 4..7
+};
+H263_DEV RowTerms row_terms(const uint32_t r[3], uint32_t sh, uint32_t ix)
+{
+    const uint32_t a0 = alignbyte(r[1], r[0], sh), a1 = alignbyte(r[2], r[1], sh), a2 = alignbyte(0u, r[2], sh);
+    const uint32_t s0 = alignbyte(a1, a0, ix), s1 = alignbyte(a2, a1, ix);
+    RowTerms t;
+    t.h[0] = lerp_u8x4(a0, s0, 0u); t.x[0] = a0 ^ s0;
+    t.h[1] = lerp_u8x4(a1, s1, 0u); t.x[1] = a1 ^ s1;
+    return t;
+}
+// One form for the four half-pel cases of gather.rs:84-132.  The pixel is (a + s + b + t + 2) >> 2 with a, s from row
+// v + j and b, t from row v + j + (mvy & 1) (repeated taps make it the two-tap average or the tap itself).  With
+// a + s = 2 Ha + la and b + t = 2 Hb + lb that is (Ha + Hb + 1 + (la & lb)) >> 1: the rounding average of the two floor
+// averages, plus one exactly where both dropped bits are set and Ha + Hb is even (an odd sum absorbs the extra one).
+// `my` = all ones for an odd vertical vector (the lower row is row j + 1), 0 else (it is row j again).
+H263_DEV uint32_t blend_rows(uint32_t ha, uint32_t xa, uint32_t hn, uint32_t xn, uint32_t my)
+{
+    const uint32_t dm = (ha ^ hn) & my;            // Ha ^ Hb
+    const uint32_t hb = ha ^ dm;
+    const uint32_t both = xa & (xn | ~my) & 0x01010101u;
+    return lerp_u8x4(ha, hb, 0x01010101u) + (both ^ (both & dm));
+}
+
+template <int N_ROWS>
+H263_DEV void predict_piece(ReconWave &s, uint32_t (*rows)[3], uint32_t mvw, uint32_t flags, const PieceGeo &g, bool all_integer,
+                            bool all_inter)
+{
+    const int mvx = (int16_t)(mvw & 0xffffu);
+    const uint32_t ix = (uint32_t)mvx & 1u, my = 0u - ((mvw >> 16) & 1u);
+    const int u = g.px + (mvx >> 1);
+    uint32_t sh = (uint32_t)u & 3u;          // the rows were loaded from the dword at or below u
+    if (flags & SEG_BORDER) {
+        // some tap lies outside the picture: rebuild the rows tap by tap from the loaded window
+        const int ub = border_window(u, g.pw);
+#pragma unroll
+        for (int j = 0; j <= N_ROWS; j++) gather_row_clamped(rows[j], u, ub, g.pw);
+        sh = 0;
+    }
+    const uint32_t keep = all_inter ? 0xffffffffu : 0u - (flags & (uint32_t)SEG_INTER);   // intra macroblocks start from zeros (gather.rs:136-138)
+    uint8_t *dst = &s.pix[g.pixoff];
+    if (all_integer) {                       // whole wave on integer vectors: the bytes are the prediction
+#pragma unroll
+        for (int j = 0; j < N_ROWS; j++) {
+            const uint32_t a0 = alignbyte(rows[j][1], rows[j][0], sh), a1 = alignbyte(rows[j][2], rows[j][1], sh);
+            *reinterpret_cast<uint64_t *>(dst + j * PIX_STRIDE) = (uint64_t)(a0 & keep) | ((uint64_t)(a1 & keep) << 32);
+        }
+        return;
+    }
+    RowTerms cur = row_terms(rows[0], sh, ix);
+#pragma unroll
+    for (int j = 0; j < N_ROWS; j++) {
+        const RowTerms nxt = row_terms(rows[j + 1], sh, ix);
+        const uint32_t lo = blend_rows(cur.h[0], cur.x[0], nxt.h[0], nxt.x[0], my);
+        const uint32_t hi = blend_rows(cur.h[1], cur.x[1], nxt.h[1], nxt.x[1], my);
+        *reinterpret_cast<uint64_t *>(dst + j * PIX_STRIDE) = (uint64_t)(lo & keep) | ((uint64_t)(hi & keep) << 32);
+        cur = nxt;
+    }
+}
+
+// MC = false: nothing is predicted anywhere in the wave: the strip starts from zeros (gather.rs:136-138).
 template <bool MC = true>
-H263_DEV void recon_phase_output(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
+H263_DEV void recon_phase_predict(const ReconArgs &a, ReconWave &s, WaveFetch &f, int lane, const WavePos &p, const WaveMasks &km)
+{
+    const PieceGeo gl = piece_geometry(a, lane, 0, p), gc = piece_geometry(a, lane, 1, p);
+    if (!MC) {
+#pragma unroll
+        for (int j = 0; j < LUMA_ROWS; j++) *reinterpret_cast<uint64_t *>(&s.pix[gl.pixoff + j * PIX_STRIDE]) = 0ull;
+#pragma unroll
+        for (int j = 0; j < CHROMA_ROWS; j++) *reinterpret_cast<uint64_t *>(&s.pix[gc.pixoff + j * PIX_STRIDE]) = 0ull;
+        return;
+    }
+    const bool all_inter = a.has_ref && km.inter == km.valid && km.valid == 0xffu;     // uniform: no lane needs zeros
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool luma_integer = __ballot(((f.mvw[0] | (f.mvw[0] >> 16)) & 1u) != 0) == 0;
+    const bool chroma_integer = __ballot(((f.mvw[1] | (f.mvw[1] >> 16)) & 1u) != 0) == 0;
+#else
+    const bool luma_integer = false, chroma_integer = false;   // (the general form covers integer vectors: checked by the CPU suite)
+#endif
+    predict_piece<LUMA_ROWS>(s, f.ly, f.mvw[0], f.flags, gl, luma_integer, all_inter);
+    predict_piece<CHROMA_ROWS>(s, f.ch, f.mvw[1], f.flags >> 2, gc, chroma_integer, all_inter);
+}
+
+// ---- phase 6: strip -> frame ---------------------------------------------------------------
+H263_DEV void recon_phase_store(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, const WaveMasks &km)
 {
     uint8_t *cur = a.cur + (size_t)p.pic * a.L.frame_bytes;
-    const uint32_t valid_mask = km.valid, act_mask = km.act;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const SegGeo g = seg_geometry(a, lane, k, p);
-        if (!((valid_mask >> g.m) & 1)) continue;
-        if (!MC) {
-            // intra macroblocks start from zeros (gather.rs:136-138): the pixels are the clipped residual, or zero
-            uint32_t lo = 0, hi = 0;
-            if ((act_mask >> g.task) & 1) {
-                const uint4 rv = *reinterpret_cast<const uint4 *>(&s.res[g.resoff]);
-                lo = add_clip_u8x4(0u, rv.x, rv.y);
-                hi = add_clip_u8x4(0u, rv.z, rv.w);
-            }
-            *reinterpret_cast<uint64_t *>(cur + g.plane_off + mad24((uint32_t)g.py, (uint32_t)g.pitch, (uint32_t)g.px)) =
-                (uint64_t)lo | ((uint64_t)hi << 32);
-            continue;
-        }
-        SegFetch sf = f.seg[k];
-        const uint32_t mvw = f.mvw[k >> 1], flags = f.flags >> (k & 2);
-        const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int16_t)(mvw >> 16);
-        const int ix = mvx & 1, iy = mvy & 1;
-        const int u = g.px + (mvx >> 1);
-        uint32_t sh = (uint32_t)u & 3u;          // the rows were loaded from the dword at or below u
-        if (flags & SEG_BORDER) {
-            // some tap lies outside the picture: rebuild the rows tap by tap from the loaded window
-            const int ub = border_window(u, g.pw);
-            gather_row_clamped(sf.r0, u, ub, g.pw);
-            if (iy) gather_row_clamped(sf.r1, u, ub, g.pw);
-            sh = 0;
-        }
-
-        // One form for the four half-pel cases of gather.rs:84-132: the right-hand taps are the bytes
-        // one further (shift by ix), the lower taps come from row v + iy, and the four-tap average of
-        // repeated taps is the two-tap average or the tap itself.
-        const uint32_t a0 = alignbyte(sf.r0[1], sf.r0[0], sh), a1 = alignbyte(sf.r0[2], sf.r0[1], sh);
-        uint32_t lo = a0, hi = a1;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (__ballot(ix | iy))             // whole wave on integer vectors: the bytes are the prediction
-#endif
-        {
-            const uint32_t a2 = alignbyte(0u, sf.r0[2], sh);
-            uint32_t b0 = a0, b1 = a1, b2 = a2;                                          // row v + iy
-            if (iy) {
-                b0 = alignbyte(sf.r1[1], sf.r1[0], sh); b1 = alignbyte(sf.r1[2], sf.r1[1], sh); b2 = alignbyte(0u, sf.r1[2], sh);
-            }
-            const uint32_t s0 = alignbyte(a1, a0, (uint32_t)ix), s1 = alignbyte(a2, a1, (uint32_t)ix);
-            const uint32_t t0 = alignbyte(b1, b0, (uint32_t)ix), t1 = alignbyte(b2, b1, (uint32_t)ix);
-            lo = avg4_u8x4(a0, s0, b0, t0);
-            hi = avg4_u8x4(a1, s1, b1, t1);
-        }
-        if (!(flags & SEG_INTER)) lo = hi = 0;             // intra macroblocks start from zeros (gather.rs:136-138)
-        if ((act_mask >> g.task) & 1) {
-            const uint4 rv = *reinterpret_cast<const uint4 *>(&s.res[g.resoff]);
-            lo = add_clip_u8x4(lo, rv.x, rv.y);
-            hi = add_clip_u8x4(hi, rv.z, rv.w);
-        }
-        const uint64_t out = (uint64_t)lo | ((uint64_t)hi << 32);
-        *reinterpret_cast<uint64_t *>(cur + g.plane_off + mad24((uint32_t)g.py, (uint32_t)g.pitch, (uint32_t)g.px)) = out;
+    for (int k = 0; k < 2; k++) {
+        const PieceGeo g = piece_geometry(a, lane, k, p);
+        if (!((km.valid >> g.m) & 1)) continue;
+        const uint32_t off = g.plane_off + mad24((uint32_t)g.py, (uint32_t)g.pitch, (uint32_t)g.px);
+        const int n_rows = k == 0 ? LUMA_ROWS : CHROMA_ROWS;
+#pragma unroll
+        for (int j = 0; j < n_rows; j++)
+            *reinterpret_cast<uint64_t *>(cur + (off + (uint32_t)(j * g.pitch))) =
+                *reinterpret_cast<const uint64_t *>(&s.pix[g.pixoff + j * PIX_STRIDE]);
     }
 }
 

@@ -57,7 +57,8 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
     a.tiles_x = (a.L.mbw + TILE_MBX - 1) / TILE_MBX;
     a.tiles_y = (a.L.mbh + TILE_MBY - 1) / TILE_MBY;
     ReconWave *s = (ReconWave *)aligned_alloc(16, (sizeof(ReconWave) + 15) / 16 * 16);
-    // same work units as kernels.hip::k_recon: XCD-ordered tiles, 4 independent waves per tile (the order of units does not matter)
+    // same work units as kernels.hip::k_recon: XCD-ordered tiles, one independent wave per macroblock row of a tile (the
+    // order of units does not matter)
     const uint32_t tpp = a.tiles_x * a.tiles_y, total = tpp * n_pictures, chunk = (total + 7) / 8;
     static WaveFetch f[64];
     for (uint32_t wg = 0; wg < chunk * 8; wg++) {
@@ -68,21 +69,21 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
             WavePos p;
             p.pic = g / tpp;
             p.mbx0 = (tile % (int)a.tiles_x) * TILE_MBX;
-            p.mby = (tile / (int)a.tiles_x) * TILE_MBY + (wave >> 1);
-            p.half = wave & 1;
+            p.mby = (tile / (int)a.tiles_x) * TILE_MBY + wave;
             if (p.mby >= (int)a.L.mbh) continue;
             p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;
             memset(s, 0xA5, sizeof *s);   // LDS is not zero-initialised on the device either
             for (int l = 0; l < 64; l++) recon_phase_load(a, *s, l, p);
             WaveMasks km;
             km.valid = recon_valid_mask(a, p);
-            km.act = km.inter = 0;
+            km.act = 0;
+            km.inter = 0;
             static TaskInfo ti[64];
             bool bad_index = false;
             for (int l = 0; l < 64; l++) {                                  // the device kernel does these reductions with ballots
                 ti[l] = recon_phase_mark(a, *s, l, p, km.valid, recon_block_limit(a, p));
-                if (ti[l].active) km.act |= 1u << l;
-                if (ti[l].inter) km.inter |= 1u << (l - WAVE_TASKS);
+                if (ti[l].active) km.act |= 1ull << l;
+                if (ti[l].inter) km.inter |= 1u << (l - MB_LANE0);
                 bad_index = bad_index || ti[l].bad_index;
             }
             for (int l = 0; l < 64; l++) recon_report(a, l, km.inter && !a.has_ref, bad_index);
@@ -93,28 +94,36 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
                 else recon_phase_fetch<false>(a, *s, f[l], l, p, km);
             }
             const int n_active = recon_n_active(km);
-            for (int round = 0; round * ROUND_BLOCKS < n_active; round++) {
+            // as kernels.hip::recon_tail: row pass of round 0, prediction into the strip, column pass of round 0, the
+            // remaining rounds, store
+            for (int round = 0; round == 0 || round * ROUND_BLOCKS < n_active; round++) {
                 static RowIn ri[64];
                 uint32_t wm = 0, rm = 0;
                 uint64_t rows_any = 0, cols_any = 0;
                 bool any_special = false;
-                for (int l = 0; l < 64; l++) {
-                    recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l], km);
-                    wm |= rowin_word_mask(ri[l]);
+                if (n_active > 0) {
+                    for (int l = 0; l < 64; l++) {
+                        recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l], km);
+                        wm |= rowin_word_mask(ri[l]);
+                    }
+                    for (int l = 0; l < 64; l++) {
+                        const RowClass rc = recon_row_class(ri[l], l);
+                        if (rc.any) { rows_any |= 1ull << l; rm |= 1u << (l & 7); }
+                        if (rc.beyond_first) cols_any |= 1ull << l;
+                    }
+                    for (int l = 0; l < 64; l++) recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm), cols_any);
+                    for (int l = 0; l < 64; l++) any_special = any_special || recon_block_is_special(ri[l], l, rows_any, cols_any);
                 }
-                for (int l = 0; l < 64; l++) {
-                    const RowClass rc = recon_row_class(ri[l], l);
-                    if (rc.any) { rows_any |= 1ull << l; rm |= 1u << (l & 7); }
-                    if (rc.beyond_first) cols_any |= 1ull << l;
+                if (round == 0) {
+                    for (int l = 0; l < 64; l++) {
+                        if (mc) recon_phase_predict<true>(a, *s, f[l], l, p, km);
+                        else recon_phase_predict<false>(a, *s, f[l], l, p, km);
+                    }
                 }
-                for (int l = 0; l < 64; l++) recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm), cols_any);
-                for (int l = 0; l < 64; l++) any_special = any_special || recon_block_is_special(ri[l], l, rows_any, cols_any);
-                for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special);
+                if (n_active > 0)
+                    for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special);
             }
-            for (int l = 0; l < 64; l++) {
-                if (mc) recon_phase_output<true>(a, *s, f[l], l, p, km);
-                else recon_phase_output<false>(a, *s, f[l], l, p, km);
-            }
+            for (int l = 0; l < 64; l++) recon_phase_store(a, *s, l, p, km);
         }
     }
     free(s);

@@ -220,9 +220,14 @@ struct h263mi_batch {
     {
         n = n_streams;
         L = make_layout(w, h);
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipMalloc((void **)&frames[i], (size_t)n * L.frame_bytes));
-            HIP_TRY(hipMemsetAsync(frames[i], 0, (size_t)n * L.frame_bytes, stream));
+        // both frame sets in ONE allocation, the second one `skew` bytes behind the first (EXPERIMENT: H263MI_FRAME_SKEW)
+        {
+            const char *e = getenv("H263MI_FRAME_SKEW");
+            const size_t skew = e ? (size_t)strtoull(e, nullptr, 0) : 0, set_bytes = (size_t)n * L.frame_bytes;
+            HIP_TRY(hipMalloc((void **)&frames[0], 2 * set_bytes + skew));
+            frames[1] = frames[0] + set_bytes + skew;
+            if (getenv("H263MI_TRACE_ALLOC")) fprintf(stderr, "h263mi frame store: %p .. +%zu\n", (void *)frames[0], 2 * set_bytes + skew);
+            HIP_TRY(hipMemsetAsync(frames[0], 0, 2 * set_bytes + skew, stream));
         }
         if (!d_status) {
             HIP_TRY(hipMalloc((void **)&d_status, sizeof(uint32_t)));
@@ -246,10 +251,8 @@ struct h263mi_batch {
 
     void release_frames()
     {
-        for (int i = 0; i < 2; i++) {
-            if (frames[i]) (void)hipFree(frames[i]);
-            frames[i] = nullptr;
-        }
+        if (frames[0]) (void)hipFree(frames[0]);         // (one allocation holds both sets)
+        frames[0] = frames[1] = nullptr;
     }
 
     ~h263mi_batch()
@@ -1375,7 +1378,7 @@ int h263mi_device_synchronize(int device_id)
     return H263MI_OK;
 }
 
-int h263mi_probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s)
+static int probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s, int *best_shape)
 {
     if (!gb_per_s || mode < 0 || mode > 2 || bytes < (1u << 20) || reps < 1) return H263MI_ERR_INVALID_ARGUMENT;
     const int dev = cfg ? cfg->device_id : 0;
@@ -1396,19 +1399,43 @@ int h263mi_probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes
         (void)hipEventDestroy(e0);
         return H263MI_ERR_HIP;
     }
-    hipError_t e = launch_probe(mode, in.p, out.p, bytes, stream);            // warm-up
-    if (e == hipSuccess) e = hipEventRecord(e0, stream);
-    for (int i = 0; i < reps && e == hipSuccess; i++) e = launch_probe(mode, in.p, out.p, bytes, stream);
-    if (e == hipSuccess) e = hipEventRecord(e1, stream);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    // every launch shape of the mode (kernels.hip: probe_shapes), the fastest one is the box's ceiling
+    hipError_t e = hipSuccess;
+    float best_ms = 0.f;
+    for (int shape = 0; shape < probe_shapes(mode) && e == hipSuccess; shape++) {
+        e = launch_probe(mode, shape, in.p, out.p, bytes, stream);          // warm-up
+        if (e == hipSuccess) e = hipEventRecord(e0, stream);
+        for (int i = 0; i < reps && e == hipSuccess; i++) e = launch_probe(mode, shape, in.p, out.p, bytes, stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (e == hipSuccess && t > 0.f && (best_ms == 0.f || t < best_ms)) {
+            best_ms = t;
+            if (best_shape) *best_shape = shape;
+        }
+    }
+    const float ms = best_ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     HIP_TRY(e);
     const double moved = (mode == 0 ? 2.0 : 1.0) * (double)bytes * reps;
     *gb_per_s = ms > 0.f ? moved / (ms * 1e-3) / 1e9 : 0.0;
     return H263MI_OK;
+}
+
+int h263mi_probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s)
+{
+    return probe_bandwidth(cfg, mode, bytes, reps, gb_per_s, nullptr);
+}
+
+int h263mi_probe_bandwidth_shape(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s,
+                                 const char **shape_name)
+{
+    int shape = 0;
+    const int rc = probe_bandwidth(cfg, mode, bytes, reps, gb_per_s, &shape);
+    if (shape_name) *shape_name = rc == H263MI_OK ? probe_shape_name(mode, shape) : "";
+    return rc;
 }
 
 int h263mi_synth_picture_host(int kind, uint16_t width, uint16_t height, uint32_t stream_id, uint32_t frame_idx,

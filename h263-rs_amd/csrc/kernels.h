@@ -43,7 +43,10 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
 hipError_t launch_post(const PostArgs &args, hipStream_t stream);
 hipError_t launch_synth_headers(const SynthArgs &args, hipStream_t stream);
 hipError_t launch_synth_coeffs(const SynthArgs &args, hipStream_t stream);
-// streaming probes: mode 0 copy in -> out, 1 read in (out = 16-byte sink), 2 write out; bytes is a multiple of 16
-hipError_t launch_probe(int mode, const void *in, void *out, size_t bytes, hipStream_t stream);
+// streaming probes: mode 0 copy in -> out, 1 read in (out = 16-byte sink), 2 write out; bytes is a multiple of 16;
+// shape < probe_shapes(mode) picks the launch shape (kernels.hip)
+int probe_shapes(int mode);
+const char *probe_shape_name(int mode, int shape);
+hipError_t launch_probe(int mode, int shape, const void *in, void *out, size_t bytes, hipStream_t stream);
 
 }  // namespace h263mi

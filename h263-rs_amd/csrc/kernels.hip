@@ -53,6 +53,100 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 // the same inside code that exists in two instantiations: the marker says which one
 #define ISA_MARK2(first, prefix_a, prefix_b, name) do { if (first) ISA_MARK(prefix_a name); else ISA_MARK(prefix_b name); } while (0)
 
+// L2 prefetch through the SCALAR cache.  Every reconstruction wave starts with a load nothing can hide: its eight
+// records, read once, always an HBM miss (a timing experiment with the records of all pictures folded into 64 KB ran
+// 10 % faster: profiles/r03_e_timing_wrap.txt).  The XCD-aware work order makes the future predictable: this XCD starts
+// the wave `q` (the caller names it: a few macroblock rows further down the same band, or the top of the band in the
+// picture the XCD takes next) two or three microseconds from now.  Three scalar loads touch the 128-byte lines of THAT
+// wave's records: scalar loads go SQC -> L2 (they occupy no slot of the CU's vector memory pipeline, which is what
+// the launch is short of) and leave the lines in this XCD's L2, where the later wave's vector load finds them.  The
+// values are never used; they are kept live until the wave's first LDS wait so that the registers are not reused while
+// the loads are in flight.
+// EXPERIMENT, compiled out (H263MI_EXP_COEF_PREFETCH): the same trick for the COEFFICIENTS (also read once, also
+// always an HBM miss, the first thing the IDCT waits for: folded into 64 KB they ran another 10 % faster) -- but one
+// scalar load per 128-byte block is up to 48 of them per wave, and the launch got SLOWER (P pictures +1.3 %, dense I
+// pictures +12 %, in-process A/B profiles/r03_f_ab_inproc_prefetch.txt).  Where they are is written in the records of the wave that
+// will read them, so it takes two steps: this wave prefetches the records of the wave 2D positions ahead (`far`), and
+// reads -- with scalar loads, out of the L2 where the wave D positions back has put them -- the coefficient range in
+// the records of the wave D positions ahead (`near`), whose 128-byte coefficient blocks it then touches one scalar
+// load each.  Those go out right behind the wave's own vector loads and are only waited for where the wave would wait
+// for its own HBM accesses anyway (scalar loads share the LDS counter: an earlier LDS wait would expose them).
+struct PrefetchPlan { WavePos far, near; };
+struct PrefetchTokens {
+    uint32_t t[3];                       // far: the three lines of its records
+    uint32_t c_first, c_last, w0_last;   // near: coeff_index of its first record, of its last record, and that record's word 0 (cbp)
+    uint64_t cbase;                      // near: coeff_base of its picture
+    bool near_ok;
+};
+typedef const __attribute__((address_space(4))) uint32_t *ScalarPtr32;
+typedef const __attribute__((address_space(4))) uint64_t *ScalarPtr64;
+__device__ __forceinline__ bool wave_exists(const ReconArgs &a, const WavePos &q)
+{
+    return q.pic >= 0 && q.pic < (int)a.n_pictures && q.mby >= 0 && q.mby < (int)a.L.mbh && q.mbx0 < (int)a.L.mbw;
+}
+__device__ __forceinline__ PrefetchTokens recon_prefetch(const ReconArgs &a, const PrefetchPlan &plan)
+{
+    PrefetchTokens k = {{0u, 0u, 0u}, 0u, 0u, 0u, 0ull, false};
+#if !defined(H263MI_NO_PREFETCH)
+    if (wave_exists(a, plan.far)) {                             // uniform
+        const WavePos &q = plan.far;
+        const int n = (int)a.L.mbw - q.mbx0;                    // records of that wave: min(n, 8)
+        const ScalarPtr32 r = (ScalarPtr32)(uintptr_t)(a.mbs + (size_t)q.pic * a.mbs_per_picture + (size_t)q.mby * a.L.mbw + q.mbx0);
+        const int last = (n < TILE_MBX ? n : TILE_MBX) * 8 - 1; // last dword of the wave's records
+        k.t[0] = r[0];
+        k.t[1] = r[last < 32 ? last : 32];
+        k.t[2] = r[last];
+    }
+#if defined(H263MI_EXP_COEF_PREFETCH)       // measured: +1.3 % on P pictures, +12 % on dense I pictures (profiles/r03_f_*): off
+    if (wave_exists(a, plan.near)) {
+        const WavePos &q = plan.near;
+        const int n = (int)a.L.mbw - q.mbx0;
+        const ScalarPtr32 r = (ScalarPtr32)(uintptr_t)(a.mbs + (size_t)q.pic * a.mbs_per_picture + (size_t)q.mby * a.L.mbw + q.mbx0);
+        const int last = (n < TILE_MBX ? n : TILE_MBX) * 8 - 1;
+        k.c_first = r[7];
+        k.w0_last = r[last - 7];
+        k.c_last = r[last];
+        k.cbase = a.coeff_base ? ((ScalarPtr64)(uintptr_t)a.coeff_base)[q.pic] : 0ull;
+        k.near_ok = true;
+    }
+#endif
+#endif
+    return k;
+}
+// the coefficient blocks of the `near` wave: [first block, number of blocks) in a.coeffs; all of it from records nobody
+// has validated yet, so the range is bounded before anything is touched
+struct CoefRange { const uint8_t *base; uint32_t lines; };
+__device__ __forceinline__ CoefRange recon_prefetch_retire(const ReconArgs &a, const PrefetchTokens &k)
+{
+    asm volatile("" :: "s"(k.t[0]), "s"(k.t[1]), "s"(k.t[2]));
+    CoefRange cr = {nullptr, 0u};
+    if (k.near_ok) {
+        const uint32_t end = k.c_last + (uint32_t)__popc((k.w0_last >> 16) & 0x3fu);
+        const uint32_t lines = end - k.c_first;                 // (wraps for nonsense records: caught by the bound)
+        const uint64_t first = k.cbase + k.c_first;
+        const bool inside = !a.coeff_checked || (first <= a.coeff_pool_blocks && lines <= a.coeff_pool_blocks - first);
+        if (lines <= (uint32_t)WAVE_TASKS && end >= k.c_first && inside) {
+            cr.base = reinterpret_cast<const uint8_t *>(a.coeffs) + first * 128u;
+            cr.lines = lines;
+        }
+    }
+    return cr;
+}
+// one scalar load per 128-byte coefficient block; the caller keeps the token alive until it has waited (lgkmcnt(0))
+__device__ __forceinline__ uint32_t recon_prefetch_lines(const CoefRange &cr)
+{
+    uint32_t tok = 0;
+    const uint8_t *p = cr.base;
+    for (uint32_t i = 0; i < cr.lines; i++, p += 128)           // uniform: a scalar loop
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tok) : "s"(p) : "memory");
+    return tok;
+}
+__device__ __forceinline__ void recon_prefetch_lines_retire(uint32_t tok)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" :: "s"(tok));
+}
+
 // ---------------------------------------------------------------------------------------
 // k_recon: one wave = 8 whole macroblocks (recon_kernel.inl), no workgroup barrier, work taken in XCD-aware order
 // (see k_post below).
@@ -106,13 +200,14 @@ __device__ __forceinline__ void recon_round_cols(ReconWave &s, int lane, const R
 // MC: some macroblock of the wave takes a prediction.
 template <bool MC>
 __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, const WaveMasks &km,
-                                           unsigned long long &t_prev_)
+                                           const CoefRange &ahead_coefs, unsigned long long &t_prev_)
 {
     (void)t_prev_;                                  // (only the diagnosis build H263MI_PROFILE_PHASES reads the clock)
     ISA_MARK2(MC, "mc_", "intra_", "tail_begin");
     int ln = lane;
     WaveFetch f;
     recon_phase_fetch<MC>(a, s, f, ln, p, km);      // every global load of this wave is in flight from here
+    const uint32_t pf_tok = recon_prefetch_lines(ahead_coefs);      // ... and the L2 prefetch for a later wave behind them
     const int n_active = recon_n_active(km);
     ISA_MARK2(MC, "mc_", "intra_", "fetch_end");
     PHASE_MARK(2);
@@ -128,6 +223,7 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     ISA_MARK2(MC, "mc_", "intra_", "predict_end");
     PHASE_MARK(4);
     wave_fence();                                   // the prediction is in the strip
+    recon_prefetch_lines_retire(pf_tok);            // (the wave's own loads have arrived: so have these)
     if (n_active > 0) recon_round_cols<MC>(s, ln, rs);
 #pragma unroll 1
     for (int round = 1; round * ROUND_BLOCKS < n_active; round++) {
@@ -143,10 +239,11 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
 }
 
 // One wave's share of the reconstruction: the 8 macroblocks at `p`.
-__device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int lane, WavePos p)
+__device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan)
 {
     if (p.mby >= (int)a.L.mbh) return;
     p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
+    const PrefetchTokens pf = recon_prefetch(a, plan);
 
 #if defined(H263MI_PROFILE_PHASES)
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -171,14 +268,15 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
     recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index != 0) != 0);
     recon_phase_compact(s, ln, ti, km.act);
     wave_fence();                                   // descriptors and chroma vectors are in LDS
+    const CoefRange ahead_coefs = recon_prefetch_retire(a, pf);
     ISA_MARK("mark_end");
     PHASE_MARK(1);
     // Two copies of the rest, chosen per wave (uniform): waves with a prediction to fetch, and waves without one --
     // every wave of an I picture -- which issue no reference loads, compute no addresses for them and skip the
     // interpolation.  Two copies rather than a switch inside one: the wait in front of the first IDCT round must
     // know how many loads were issued behind the coefficient row.
-    if (a.has_ref && km.inter) recon_tail<true>(a, s, ln, p, km, t_prev_);
-    else recon_tail<false>(a, s, ln, p, km, t_prev_);
+    if (a.has_ref && km.inter) recon_tail<true>(a, s, ln, p, km, ahead_coefs, t_prev_);
+    else recon_tail<false>(a, s, ln, p, km, ahead_coefs, t_prev_);
     PHASE_MARK(6);
 }
 
@@ -204,7 +302,9 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     p.mbx0 = (int)tile_x * TILE_MBX;
     p.mby = (int)tile_y * TILE_MBY + tw;
     p.cbase = 0;
-    recon_wave(a, waves[wave], lane, p);
+    PrefetchPlan plan = {p, p};
+    plan.far.pic = plan.near.pic = -1;              // (no prefetch in the stand-alone kernel)
+    recon_wave(a, waves[wave], lane, p, plan);
 }
 
 // Bands per picture: the XCDs that share one picture's work list (k_recon, k_frame).  Measured on the 64-stream bench
@@ -212,6 +312,11 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
 // 1.5-3 % faster (fewer band borders, whose reference rows two L2s fetch), 2 bands 326 MB (the algorithmic reads are
 // 317 MB) but run no faster than 8, 1 band (a picture per XCD) is 4 % slower.  Small batches keep 8 bands: with fewer,
 // 8 / bands pictures are needed to occupy every XCD.
+// Prefetch distance of k_frame's reconstruction waves, in groups of the work list (recon_prefetch): far enough for an HBM
+// access to complete before the target wave starts, near enough for the lines to survive in the XCD's 4 MB of L2.
+#ifndef H263MI_PF_GROUPS
+#define H263MI_PF_GROUPS 3
+#endif
 #ifndef H263MI_FRAME_BANDS
 #define H263MI_FRAME_BANDS 4
 #endif
@@ -372,7 +477,28 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
         p.mbx0 = (int)(r >> 1) * TILE_MBX;
         p.mby = (int)group * TILE_MBY + (int)(r & 1);
         p.cbase = 0;
-        recon_wave(ra, lds.r, lane, p);
+        // Which waves to prefetch for (recon_prefetch): `near` = the wave H263MI_PF_GROUPS groups further down this band's
+        // list (same tile column, same macroblock row parity), `far` = twice as far; past the end of the band, the item
+        // that far into the band of the picture this XCD takes next, when that item is a reconstruction wave.
+        PrefetchPlan plan = {p, p};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            WavePos &q = k ? plan.far : plan.near;
+            const uint32_t dist = (k ? 2u : 1u) * H263MI_PF_GROUPS;
+            const uint32_t g2 = g + dist * per_group, band_end = (band + 1) * chunk < upp ? (band + 1) * chunk : upp;
+            if (g2 < band_end) {
+                q.mby = p.mby + (int)dist * TILE_MBY;
+            } else {
+                const uint32_t g3 = g2 - band_end + band * chunk;          // counted from the start of the band
+                const uint32_t group3 = div_tiles_x(g3, per_group, fg.inv_per_group), r3 = g3 - group3 * per_group;
+                const int pic3 = ((int)blockIdx.y + 1) * (int)(8 / bands) + (int)side;
+                q.pic = r3 < fg.recon_per_group && pic3 < (int)ra.n_pictures
+                            ? (fg.flip ? (int)ra.n_pictures - 1 - pic3 : pic3) : -1;
+                q.mbx0 = (int)(r3 >> 1) * TILE_MBX;
+                q.mby = (int)group3 * TILE_MBY + (int)(r3 & 1);
+            }
+        }
+        recon_wave(ra, lds.r, lane, p, plan);
     } else {
         if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
 #if defined(H263MI_EXP_PLAIN_RGBA)
@@ -511,35 +637,69 @@ hipError_t launch_synth_coeffs(const SynthArgs &a, hipStream_t stream)
 }
 
 // ---------------------------------------------------------------------------------------
-// on-box memory ceilings (bench support: roofline.peak_measured).  Plain grid-stride streaming kernels with
-// 16-byte accesses: the rate the HBM system of THIS box sustains for a copy, a pure read and a pure write.
+// on-box memory ceilings (bench support: roofline.peak_measured).  Streaming kernels with 16-byte accesses: the rate the
+// HBM system of THIS box sustains for a copy, a pure read and a pure write.  Round 2's plain grid-stride probes
+// (2 048 workgroups, one access per iteration) reported 4.8 TB/s for a copy where the MI355X guide measures 6.29:
+// tools/probes/ceiling.hip swept the launch shape (profiles/r03_a_ceiling_probe.txt) -- what reaches 6.2 TB/s is
+// non-temporal accesses, four of them in flight per lane (copy); a read wants non-temporal loads, a write is fastest
+// with few (256) workgroups of plain stores.  `shape` selects among the winners; the C entry point reports the best.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_probe_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE, int U, bool NT>
+__global__ __launch_bounds__(1024) void k_probe(const probe_u32x4 *__restrict__ in, probe_u32x4 *__restrict__ out, size_t n)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
-}
-__global__ __launch_bounds__(256) void k_probe_read(const uint4 *__restrict__ in, uint4 *__restrict__ sink, size_t n)
-{
-    uint32_t acc = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 v = in[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    // a workgroup walks the buffer in steps of gridDim * blockDim * U elements; its U accesses of a step are blockDim apart
+    const size_t step = (size_t)gridDim.x * blockDim.x * U;
+    probe_u32x4 acc = {0, 0, 0, 0};
+    for (size_t base = (size_t)blockIdx.x * blockDim.x * U + threadIdx.x; base < n; base += step) {
+        probe_u32x4 v[U];
+        if (MODE != 2) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const size_t i = base + (size_t)u * blockDim.x;
+                v[u] = i < n ? (NT ? __builtin_nontemporal_load(in + i) : in[i]) : acc;
+            }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) acc ^= v[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const size_t i = base + (size_t)u * blockDim.x;
+                if (MODE == 2) v[u] = probe_u32x4{(uint32_t)i, 1, 2, 3};
+                if (i < n) {
+                    if (NT) __builtin_nontemporal_store(v[u], out + i);
+                    else out[i] = v[u];
+                }
+            }
+        }
     }
-    if (acc == 0x12345678u) sink[0] = make_uint4(acc, 0, 0, 0);      // never true for the probe's fill pattern
-}
-__global__ __launch_bounds__(256) void k_probe_write(uint4 *__restrict__ out, size_t n)
-{
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = make_uint4((uint32_t)i, 1, 2, 3);
+    if (MODE == 1 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = acc;      // never true for the probe's fill pattern
 }
 
-hipError_t launch_probe(int mode, const void *in, void *out, size_t bytes, hipStream_t stream)
+int probe_shapes(int mode) { return mode == 0 ? 2 : mode == 1 ? 2 : 3; }
+const char *probe_shape_name(int mode, int shape)
+{
+    static const char *names[3][3] = {
+        {"non-temporal, 4 accesses in flight, 4096 x 256 threads", "non-temporal, 4 accesses in flight, 256 x 512 threads", ""},
+        {"non-temporal loads, 4 in flight, 256 x 512 threads", "non-temporal loads, 512 x 1024 threads", ""},
+        {"plain stores, 256 x 256 threads", "plain stores, 8 per iteration, 256 x 1024 threads", "non-temporal stores, 256 x 256 threads"}};
+    return names[mode][shape];
+}
+
+hipError_t launch_probe(int mode, int shape, const void *in, void *out, size_t bytes, hipStream_t stream)
 {
     const size_t n = bytes / 16;
-    const dim3 grid(256 * 8), block(256);
-    if (mode == 0) hipLaunchKernelGGL(k_probe_copy, grid, block, 0, stream, (const uint4 *)in, (uint4 *)out, n);
-    else if (mode == 1) hipLaunchKernelGGL(k_probe_read, grid, block, 0, stream, (const uint4 *)in, (uint4 *)out, n);
-    else hipLaunchKernelGGL(k_probe_write, grid, block, 0, stream, (uint4 *)out, n);
+    const probe_u32x4 *pi = (const probe_u32x4 *)in;
+    probe_u32x4 *po = (probe_u32x4 *)out;
+    if (mode == 0 && shape == 0) hipLaunchKernelGGL((k_probe<0, 4, true>), dim3(4096), dim3(256), 0, stream, pi, po, n);
+    else if (mode == 0) hipLaunchKernelGGL((k_probe<0, 4, true>), dim3(256), dim3(512), 0, stream, pi, po, n);
+    else if (mode == 1 && shape == 0) hipLaunchKernelGGL((k_probe<1, 4, true>), dim3(256), dim3(512), 0, stream, pi, po, n);
+    else if (mode == 1) hipLaunchKernelGGL((k_probe<1, 1, true>), dim3(512), dim3(1024), 0, stream, pi, po, n);
+    else if (shape == 0) hipLaunchKernelGGL((k_probe<2, 1, false>), dim3(256), dim3(256), 0, stream, pi, po, n);
+    else if (shape == 1) hipLaunchKernelGGL((k_probe<2, 8, false>), dim3(256), dim3(1024), 0, stream, pi, po, n);
+    else hipLaunchKernelGGL((k_probe<2, 1, true>), dim3(256), dim3(256), 0, stream, pi, po, n);
     return hipGetLastError();
 }
 

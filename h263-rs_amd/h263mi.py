@@ -66,6 +66,7 @@ EXPORTS = [
     "h263mi_batch_decode", "h263mi_batch_decode_next_pictures",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
     "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_timing_reserve", "h263mi_probe_bandwidth",
+    "h263mi_probe_bandwidth_shape",
     "h263mi_batch_submit_host", "h263mi_submit_picture_events", "h263mi_batch_submit_host_events",
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
@@ -160,6 +161,7 @@ def lib():
         L.h263mi_batch_timing_end.argtypes = [vp, C.POINTER(KernelTimes)]
         L.h263mi_batch_timing_reserve.argtypes = [vp, u32]
         L.h263mi_probe_bandwidth.argtypes = [C.POINTER(BackendCfg), i32, sz, i32, C.POINTER(C.c_double)]
+        L.h263mi_probe_bandwidth_shape.argtypes = [C.POINTER(BackendCfg), i32, sz, i32, C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
         L.h263mi_device_count.argtypes = [C.POINTER(i32)]
         L.h263mi_device_malloc.argtypes = [i32, sz, C.POINTER(vp)]
         L.h263mi_device_free.argtypes = [i32, vp]
@@ -477,10 +479,15 @@ class Batch:
 PROBE_COPY, PROBE_READ, PROBE_WRITE = 0, 1, 2
 
 
-def probe_bandwidth(mode, nbytes=1 << 30, reps=10, device_id=0, stream=None):
-    """GB/s the device sustains for a plain streaming copy / read / write kernel (h263mi_probe_bandwidth)."""
+def probe_bandwidth(mode, nbytes=1 << 30, reps=10, device_id=0, stream=None, with_shape=False):
+    """GB/s the device sustains for a streaming copy / read / write kernel: the fastest of the library's launch shapes
+    (h263mi_probe_bandwidth); with_shape: (GB/s, description of the shape that won)."""
     cfg = BackendCfg(device_id, 0, stream)
     out = C.c_double(0.0)
+    if with_shape:
+        name = C.c_char_p()
+        _check(lib().h263mi_probe_bandwidth_shape(C.byref(cfg), mode, nbytes, reps, C.byref(out), C.byref(name)), "probe_bandwidth")
+        return out.value, (name.value or b"").decode()
     _check(lib().h263mi_probe_bandwidth(C.byref(cfg), mode, nbytes, reps, C.byref(out)), "probe_bandwidth")
     return out.value
 

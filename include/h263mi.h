@@ -363,12 +363,16 @@ int h263mi_device_memcpy_d2h(int device_id, void *dst, const void *src, size_t b
 int h263mi_device_synchronize(int device_id);
 
 /* On-box memory ceiling of the device (bench support, BASELINE.md section 4 "measure an on-box copy-kernel
- * ceiling"): streams `bytes` through a plain grid-stride kernel `reps` times on cfg's stream and reports the rate.
- * mode 0: copy (bytes read + bytes written are both counted), 1: read only, 2: write only. */
+ * ceiling"): streams `bytes` through a streaming kernel `reps` times on cfg's stream, in each of a few launch shapes
+ * (non-temporal / plain 16-byte accesses, 1 to 8 in flight per lane, 256 to 4096 workgroups: the winners of the sweep
+ * in tools/probes/ceiling.hip), and reports the rate of the fastest.  mode 0: copy (bytes read + bytes written are both
+ * counted), 1: read only, 2: write only.  h263mi_probe_bandwidth_shape also names the shape that won. */
 #define H263MI_PROBE_COPY  0
 #define H263MI_PROBE_READ  1
 #define H263MI_PROBE_WRITE 2
 int h263mi_probe_bandwidth(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s);
+int h263mi_probe_bandwidth_shape(const h263mi_backend_cfg *cfg, int mode, size_t bytes, int reps, double *gb_per_s,
+                                 const char **shape_name);
 
 #define H263MI_SYNTH_I_DENSE 0  /* BASELINE config 2 "dense": every block Full */
 #define H263MI_SYNTH_I_MIXED 1  /* config 2 "mixed": Dc / Horiz / Vert / Full-dense / Full-sparse */

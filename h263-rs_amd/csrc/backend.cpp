@@ -4,6 +4,8 @@
 // kernels.hip -- there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <new>
 #include <algorithm>
 #include <atomic>
@@ -164,23 +166,35 @@ struct h263mi_batch {
         bool valid = false;
         uint8_t strength = 0;
         uint8_t *rgba = nullptr, *planes = nullptr;
-        int set = -1;                          // frame set it reads
+        std::vector<int8_t> set;               // per stream: frame set it reads, -1 = nothing to post-process
     } pending;
     uint32_t n = 0;
     FrameLayout L{};
     uint8_t *frames[2] = {nullptr, nullptr};   // ping-pong frame sets, n * frame_bytes each
-    int cur = -1;                              // frame set holding the last picture, -1 = none
-    bool has_ref = false;                      // state.rs:29-31 reference_picture.is_some()
-    uint32_t *d_status = nullptr;
+    // Every stream of the batch is its own H263State (state.rs:16-50): its own last picture, its own reference flag,
+    // its own errors.  As long as all streams agree (the common case: they advance in lock step and nothing fails) the
+    // kernels get one set of pointers; once they differ, a word per stream (dev_common.h: STREAM_*).
+    struct StreamState {
+        int8_t cur = -1;                       // frame set holding the stream's last picture, -1 = none
+        bool has_ref = false;                  // state.rs:29-31 reference_picture.is_some()
+        int8_t good_cur = -1;                  // ... as of the last successful sync (what an error falls back to)
+        bool good_has_ref = false;
+        uint32_t unsynced = 0;                 // pictures submitted since then
+        bool active = true;                    // takes part in the next submit (h263mi_batch_set_active)
+    };
+    std::vector<StreamState> ss;
+    uint32_t *d_status = nullptr;              // one word per stream
     uint32_t *h_status = nullptr;              // pinned
+    // per-stream words for the kernels: a small ring of pinned host slots + one device array per slot
+    static constexpr unsigned kStateSlots = 4;
+    uint32_t *h_state = nullptr, *d_state = nullptr;
+    hipEvent_t state_copied[kStateSlots] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned state_slot = 0;
     uint64_t coeff_pool_blocks = 0;            // size of the pool the next submit reads ...
     bool coeff_checked = false;                // ... when the caller told us (host entry points do; device pointers do not)
-    // what sync() falls back to when the device reports an error (state.rs:142, 464-487: an error leaves the state
-    // unchanged): the bookkeeping as of the last successful sync, valid as long as at most one picture was
-    // submitted since (the frame set it names is the one the ping-pong has not overwritten yet)
-    int good_cur = -1;
-    bool good_has_ref = false;
-    unsigned unsynced_submits = 0;
+    // (what sync() falls back to when the device reports an error -- state.rs:142, 464-487: an error leaves the state
+    // unchanged -- is each stream's good_cur / good_has_ref, valid as long as at most one picture was submitted for the
+    // stream since: the frame set it names is the one the ping-pong has not overwritten yet)
     unsigned frame_launches = 0;               // k_frame launches so far: odd ones walk the pictures backwards
     // host-record staging for h263mi_batch_submit_host: two slots (pinned host + device) used alternately, so
     // that packing picture i+1 overlaps the copy and the kernel of picture i
@@ -220,33 +234,80 @@ struct h263mi_batch {
     {
         n = n_streams;
         L = make_layout(w, h);
-        // both frame sets in ONE allocation, the second one `skew` bytes behind the first (EXPERIMENT: H263MI_FRAME_SKEW)
+        // both frame sets in one allocation
         {
-            const char *e = getenv("H263MI_FRAME_SKEW");
-            const size_t skew = e ? (size_t)strtoull(e, nullptr, 0) : 0, set_bytes = (size_t)n * L.frame_bytes;
-            HIP_TRY(hipMalloc((void **)&frames[0], 2 * set_bytes + skew));
-            frames[1] = frames[0] + set_bytes + skew;
-            if (getenv("H263MI_TRACE_ALLOC")) fprintf(stderr, "h263mi frame store: %p .. +%zu\n", (void *)frames[0], 2 * set_bytes + skew);
-            HIP_TRY(hipMemsetAsync(frames[0], 0, 2 * set_bytes + skew, stream));
+            const size_t set_bytes = (size_t)n * L.frame_bytes;
+            HIP_TRY(hipMalloc((void **)&frames[0], 2 * set_bytes));
+            frames[1] = frames[0] + set_bytes;
+            HIP_TRY(hipMemsetAsync(frames[0], 0, 2 * set_bytes, stream));
         }
         if (!d_status) {
-            HIP_TRY(hipMalloc((void **)&d_status, sizeof(uint32_t)));
-            HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&d_status, (size_t)n * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc((void **)&h_status, (size_t)n * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&d_state, (size_t)n * kStateSlots * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc((void **)&h_state, (size_t)n * kStateSlots * sizeof(uint32_t), hipHostMallocDefault));
+            for (hipEvent_t &e : state_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
-        cur = good_cur = -1;
-        has_ref = good_has_ref = false;
-        unsynced_submits = 0;
+        HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n * sizeof(uint32_t), stream));
+        ss.assign(n, StreamState());
+        pending.set.assign(n, -1);
         return H263MI_OK;
     }
 
-    void forget_pictures()
+    // ---- views of the per-stream state -----------------------------------------------------------------------
+    bool any_picture() const
     {
-        (void)flush_pending();                 // what was asked to be rendered still is
-        cur = good_cur = -1;
-        has_ref = good_has_ref = false;
-        unsynced_submits = 0;
+        for (const StreamState &t : ss)
+            if (t.cur >= 0) return true;
+        return false;
+    }
+    // every stream takes part and all agree on (cur, has_ref): the kernels need no per-stream words
+    bool uniform() const
+    {
+        for (const StreamState &t : ss)
+            if (!t.active || t.cur != ss[0].cur || t.has_ref != ss[0].has_ref) return false;
+        return true;
+    }
+    bool pending_uniform() const
+    {
+        for (int8_t v : pending.set)
+            if (v != pending.set[0]) return false;
+        return true;
+    }
+    // hand the kernels one word per stream: fills the next slot of the ring and queues its copy
+    int push_stream_words(const std::vector<uint32_t> &words, const uint32_t **d_out)
+    {
+        const unsigned slot = state_slot++ % kStateSlots;
+        HIP_TRY(hipEventSynchronize(state_copied[slot]));         // (its previous copy has left the host buffer)
+        uint32_t *h = h_state + (size_t)slot * n, *d = d_state + (size_t)slot * n;
+        memcpy(h, words.data(), (size_t)n * sizeof(uint32_t));
+        RC_TRY(time_close());                                      // a copy is not part of any kernel's time
+        HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(state_copied[slot], stream));
+        *d_out = d;
+        return H263MI_OK;
+    }
+
+    int forget_pictures()
+    {
+        const int rc = flush_pending();        // what was asked to be rendered still is
+        for (StreamState &t : ss) {
+            const bool active = t.active;
+            t = StreamState();
+            t.active = active;
+        }
         parser_ctx.clear();
+        return rc;
+    }
+    // one stream forgets its pictures (the seeking rule of state.rs:134-137 for a single H263State of the batch)
+    int forget_stream(uint32_t i)
+    {
+        RC_TRY(flush_pending());
+        const bool active = ss[i].active;
+        ss[i] = StreamState();
+        ss[i].active = active;
+        if (i < parser_ctx.size()) parser_ctx[i] = bits::ParserContext();
+        return H263MI_OK;
     }
 
     void release_frames()
@@ -273,6 +334,10 @@ struct h263mi_batch {
             if (e) (void)hipEventDestroy(e);
         if (d_status) (void)hipFree(d_status);
         if (h_status) (void)hipHostFree(h_status);
+        if (d_state) (void)hipFree(d_state);
+        if (h_state) (void)hipHostFree(h_state);
+        for (hipEvent_t e : state_copied)
+            if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (HostStaging &g2 : host_stg) {
             if (g2.h_mbs) (void)hipHostFree(g2.h_mbs);
@@ -375,34 +440,70 @@ struct h263mi_batch {
     }
     int time_end(int) { return H263MI_OK; }      // (the end of a chain is recorded when it is closed)
 
-    // state.rs:432-483 for every stream of the batch.  post: the deferred post-processing to run in the same launch
-    // (pipeline mode), or null.
+    // state.rs:432-483 for every stream of the batch that takes part.  types: one picture type per stream, or nullptr:
+    // `picture_type` for all.  with_post: run the deferred post-processing (pending) in the same launch (pipeline mode).
     int submit(uint8_t picture_type, const MbRecord *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
-               const PostArgs *post = nullptr)
+               bool with_post = false, const uint8_t *types = nullptr)
     {
-        if (!post) RC_TRY(flush_pending());
-        const int out = cur < 0 ? 0 : (cur ^ 1);
+        if (!with_post) RC_TRY(flush_pending());
         ReconArgs a{};
         a.L = L;
         a.mbs = d_mbs;
         a.coeffs = d_coeffs;
         a.coeff_base = d_coeff_base;
-        // get_reference_picture() hands out the LAST picture whenever a reference exists (state.rs:72-78)
-        a.ref = frames[cur < 0 ? 1 : cur];
-        a.cur = frames[out];
         a.status = d_status;
         a.coeff_pool_blocks = coeff_pool_blocks;
         a.coeff_checked = coeff_checked ? 1u : 0u;
         a.n_pictures = n;
         a.mbs_per_picture = L.mbw * L.mbh;
-        a.has_ref = (has_ref && cur >= 0) ? 1u : 0u;
         a.tiles_x = recon_tiles_x(L);
         a.tiles_y = recon_tiles_y(L);
+        a.frame_set[0] = frames[0];
+        a.frame_set[1] = frames[1];
+        PostArgs pa{};
+        if (with_post) pa = post_args(0, pending.strength, pending.rgba, pending.planes);
+        const bool all_same = uniform() && (!with_post || (pending_uniform() && pending.set[0] >= 0));
+        int out0 = 0;
+        if (all_same) {
+            const int cur = ss[0].cur;
+            out0 = cur < 0 ? 0 : (cur ^ 1);
+            // get_reference_picture() hands out the LAST picture whenever a reference exists (state.rs:72-78)
+            a.ref = frames[cur < 0 ? 1 : cur];
+            a.cur = frames[out0];
+            a.has_ref = (ss[0].has_ref && cur >= 0) ? 1u : 0u;
+            if (with_post) pa.frames = frames[pending.set[0]];
+        } else {
+            std::vector<uint32_t> words(n);
+            for (uint32_t i = 0; i < n; i++) {
+                const StreamState &t = ss[i];
+                uint32_t w = (t.cur != 0 ? STREAM_REF_SET1 : 0u) | ((t.has_ref && t.cur >= 0) ? STREAM_HAS_REF : 0u) |
+                             (t.active ? 0u : STREAM_RECON_SKIP);
+                if (!with_post || pending.set[i] < 0) w |= STREAM_POST_SKIP;
+                else if (pending.set[i] == 1) w |= STREAM_POST_SET1;
+                words[i] = w;
+            }
+            const uint32_t *d_words = nullptr;
+            RC_TRY(push_stream_words(words, &d_words));
+            a.stream_state = d_words;
+            a.ref = frames[0];                   // (never used with stream_state; never null)
+            a.cur = frames[1];
+            if (with_post) {
+                pa.stream_state = d_words;
+                pa.frame_set[0] = frames[0];
+                pa.frame_set[1] = frames[1];
+                pa.frames = frames[0];
+            }
+        }
         // the set being overwritten was last read by the post-processing of the picture before the last one
-        if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out], 0));
-        if (post) {
+        if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out0], 0));
+        if (with_post) {
             RC_TRY(time_begin(2));
-            HIP_TRY(launch_frame(a, *post, stream, (frame_launches++ & 1u) != 0));
+            const hipError_t e = launch_frame(a, pa, stream, (frame_launches++ & 1u) != 0);
+            if (e != hipSuccess) {               // the deferred post-processing must not get lost with the failed launch
+                (void)flush_pending();
+                return map_hip_error(e);
+            }
+            pending.valid = false;
             RC_TRY(time_end(2));
         } else {
             RC_TRY(time_begin(0));
@@ -410,11 +511,16 @@ struct h263mi_batch {
             RC_TRY(time_end(0));
         }
         if (overlap_post) HIP_TRY(hipEventRecord(ev_recon_done, stream));
-        // reference bookkeeping, state.rs:464-483
-        unsynced_submits++;
-        if (picture_type == H263MI_PICTURE_I) has_ref = false;
-        cur = out;
-        if (picture_type != H263MI_PICTURE_DISPOSABLE_P) has_ref = true;
+        // reference bookkeeping, state.rs:464-483, per stream
+        for (uint32_t i = 0; i < n; i++) {
+            StreamState &t = ss[i];
+            if (!t.active) continue;
+            const uint8_t type = types ? types[i] : picture_type;
+            t.unsynced++;
+            if (type == H263MI_PICTURE_I) t.has_ref = false;
+            t.cur = (int8_t)(t.cur < 0 ? 0 : (t.cur ^ 1));
+            if (type != H263MI_PICTURE_DISPOSABLE_P) t.has_ref = true;
+        }
         return H263MI_OK;
     }
 
@@ -432,70 +538,105 @@ struct h263mi_batch {
         return a;
     }
 
+    // k_post over `sets` (per stream: the frame set to read, -1 = skip the stream)
+    int launch_post_sets(const std::vector<int8_t> &sets, uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, hipStream_t on)
+    {
+        bool same = true, any = false;
+        for (int8_t v : sets) {
+            same = same && v == sets[0];
+            any = any || v >= 0;
+        }
+        if (!any) return H263MI_OK;
+        PostArgs a = post_args(sets[0] >= 0 ? sets[0] : 0, strength, d_rgba, d_planes);
+        if (!same) {
+            std::vector<uint32_t> words(n);
+            for (uint32_t i = 0; i < n; i++)
+                words[i] = STREAM_RECON_SKIP | (sets[i] < 0 ? STREAM_POST_SKIP : (sets[i] == 1 ? STREAM_POST_SET1 : 0u));
+            const uint32_t *d_words = nullptr;
+            RC_TRY(push_stream_words(words, &d_words));
+            a.stream_state = d_words;
+            a.frame_set[0] = frames[0];
+            a.frame_set[1] = frames[1];
+        }
+        RC_TRY(time_begin(1));
+        HIP_TRY(launch_post(a, on));
+        RC_TRY(time_end(1));
+        return H263MI_OK;
+    }
+
+    // pipeline mode: the post-processing of the pictures just submitted is deferred to the next launch
+    void note_pending(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
+    {
+        pending.valid = d_rgba || d_planes;
+        pending.strength = strength;
+        pending.rgba = d_rgba;
+        pending.planes = d_planes;
+        for (uint32_t i = 0; i < n; i++) pending.set[i] = ss[i].active ? ss[i].cur : (int8_t)-1;
+    }
+
     // the deferred post-processing of pipeline mode, as a launch of its own
     int flush_pending()
     {
         if (!pending.valid) return H263MI_OK;
         pending.valid = false;
-        const PostArgs a = post_args(pending.set, pending.strength, pending.rgba, pending.planes);
-        RC_TRY(time_begin(1));
-        HIP_TRY(launch_post(a, stream));
-        RC_TRY(time_end(1));
-        return H263MI_OK;
+        return launch_post_sets(pending.set, pending.strength, pending.rgba, pending.planes, stream);
     }
 
     int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
     {
-        if (cur < 0) return H263MI_ERR_NO_PICTURE;
+        if (!any_picture()) return H263MI_ERR_NO_PICTURE;
         if (strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
         RC_TRY(flush_pending());
-        const PostArgs a = post_args(cur, strength, d_rgba, d_planes);
+        std::vector<int8_t> sets(n);
+        for (uint32_t i = 0; i < n; i++) sets[i] = ss[i].cur;
         if (overlap_post) HIP_TRY(hipStreamWaitEvent(post_stream, ev_recon_done, 0));
-        RC_TRY(time_begin(1));
-        HIP_TRY(launch_post(a, stream_of(1)));
-        RC_TRY(time_end(1));
-        if (overlap_post) HIP_TRY(hipEventRecord(ev_post_done[cur], post_stream));
+        RC_TRY(launch_post_sets(sets, strength, d_rgba, d_planes, stream_of(1)));
+        if (overlap_post) HIP_TRY(hipEventRecord(ev_post_done[ss[0].cur >= 0 ? ss[0].cur : 0], post_stream));
         return H263MI_OK;
     }
 
-    int sync()
+    // stream_rc (may be null): per stream 0, H263MI_ERR_UNCODED_IFRAME_BLOCKS or H263MI_ERR_INVALID_ARGUMENT
+    int sync(int *stream_rc = nullptr)
     {
         RC_TRY(flush_pending());
         RC_TRY(time_close());
         if (overlap_post) HIP_TRY(hipStreamSynchronize(post_stream));
-        HIP_TRY(hipMemcpyAsync(h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_status, d_status, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        uint32_t st = *h_status;
-        if (st) {
-            // A picture the device rejected must not become the last / reference picture.  One picture since the
-            // last good sync: the previous frame set is intact, go back to it.  More than one: the set it lived in
-            // has been overwritten by the ping-pong, so no picture survives (like a reset).
-            if (unsynced_submits <= 1) {
-                cur = good_cur;
-                has_ref = good_has_ref;
-            } else {
-                cur = -1;
-                has_ref = false;
+        int first_error = H263MI_OK;
+        for (uint32_t i = 0; i < n; i++) {
+            StreamState &t = ss[i];
+            const uint32_t st = h_status[i];
+            int rc = H263MI_OK;
+            if (st) {
+                // A picture the device rejected must not become the stream's last / reference picture.  One picture since
+                // the last good sync: the previous frame set is intact, go back to it.  More than one: the set it lived
+                // in has been overwritten by the ping-pong, so no picture survives (like a reset of the stream).
+                if (t.unsynced <= 1) {
+                    t.cur = t.good_cur;
+                    t.has_ref = t.good_has_ref;
+                } else {
+                    t.cur = -1;
+                    t.has_ref = false;
+                }
+                rc = (st & STATUS_INTER_WITHOUT_REFERENCE) ? H263MI_ERR_UNCODED_IFRAME_BLOCKS : H263MI_ERR_INVALID_ARGUMENT;
+                if (first_error == H263MI_OK) first_error = rc;
             }
-            good_cur = cur;
-            good_has_ref = has_ref;
-            unsynced_submits = 0;
-            HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
-            if (st & STATUS_INTER_WITHOUT_REFERENCE) return H263MI_ERR_UNCODED_IFRAME_BLOCKS;
-            return H263MI_ERR_INVALID_ARGUMENT;
+            t.good_cur = t.cur;
+            t.good_has_ref = t.has_ref;
+            t.unsynced = 0;
+            if (stream_rc) stream_rc[i] = rc;
         }
-        good_cur = cur;
-        good_has_ref = has_ref;
-        unsynced_submits = 0;
-        return H263MI_OK;
+        if (first_error != H263MI_OK) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n * sizeof(uint32_t), stream));
+        return first_error;
     }
 
     int copy_yuv(uint32_t s, uint8_t *y, uint8_t *cb, uint8_t *cr)
     {
-        if (cur < 0) return H263MI_ERR_NO_PICTURE;
         if (s >= n) return H263MI_ERR_INVALID_ARGUMENT;
+        if (ss[s].cur < 0) return H263MI_ERR_NO_PICTURE;
         RC_TRY(time_close());
-        const uint8_t *f = frames[cur] + (size_t)s * L.frame_bytes;
+        const uint8_t *f = frames[ss[s].cur] + (size_t)s * L.frame_bytes;
         // DecodedPicture planes are exact-size and tightly packed (picture.rs:39-58)
         if (y) HIP_TRY(hipMemcpy2DAsync(y, L.width, f, L.pitch_y, L.width, L.height, hipMemcpyDeviceToHost, stream));
         if (cb) HIP_TRY(hipMemcpy2DAsync(cb, L.cwidth, f + L.off_cb, L.pitch_c, L.cwidth, L.cheight, hipMemcpyDeviceToHost, stream));
@@ -703,18 +844,8 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
     if (b->pipeline_post) {
         // this picture's reconstruction and the previous picture's post-processing in one launch; this picture's
         // post-processing waits for the next call (or the next sync)
-        if (b->pending.valid && b->pending.set == b->cur) {
-            const PostArgs pa = b->post_args(b->pending.set, b->pending.strength, b->pending.rgba, b->pending.planes);
-            b->pending.valid = false;
-            RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base, &pa));
-        } else {
-            RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
-        }
-        b->pending.valid = d_rgba || d_deblocked;
-        b->pending.strength = strength;
-        b->pending.rgba = d_rgba;
-        b->pending.planes = d_deblocked;
-        b->pending.set = b->cur;
+        RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base, /*with_post=*/b->pending.valid));
+        b->note_pending(strength, d_rgba, d_deblocked);
         return H263MI_OK;
     }
     RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
@@ -729,7 +860,8 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
 static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
                              const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks,
                              const uint32_t *const *first_event, const uint32_t *const *events, const uint32_t *n_events,
-                             bool from_parser = false, uint32_t pack_threads = 0)
+                             bool from_parser = false, uint32_t pack_threads = 0, const uint8_t *types = nullptr,
+                             bool deferred_post = false)
 {
     // from_parser: the arrays are what bits::parse_picture just wrote (h263mi_batch_decode_next_pictures) -- valid by
     // construction, so the per-record checks a caller's arrays get are skipped; pack_threads: the caller's thread budget
@@ -747,6 +879,8 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                            (n_events[i] && !events[i])))
                 return H263MI_ERR_INVALID_ARGUMENT;
         }
+        // block offsets inside a stream's share of the pool are 32-bit byte offsets on the device (recon_block_limit)
+        if (n_coeff_blocks[i] > (1u << 25)) return H263MI_ERR_INVALID_ARGUMENT;
         blocks += n_coeff_blocks[i];
         if (sparse) n_ev += n_events[i];
     }
@@ -831,7 +965,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     }
     b->coeff_pool_blocks = blocks;
     b->coeff_checked = true;
-    RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base));
+    RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types));
     HIP_TRY(hipEventRecord(g2.done, b->stream));
     b->host_slot++;
     if (b->trace_host) {
@@ -860,13 +994,37 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type, const
     return batch_submit_host(b, picture_type, mbs, n_mbs, nullptr, n_coeff_blocks, block_first_event, events, n_events);
 }
 
-int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
-                                      const size_t *len, size_t *consumed, uint32_t n_threads)
+}  // extern "C"
+
+// threads the parser tasks may use when the caller does not say: the hardware threads, the affinity mask and the CPU
+// quota of the container, whichever is smallest (more runnable threads than the quota allows only get throttled: 16
+// parser threads beat 128 on a 16-CPU quota, tools/probes/cpu_scaling.py)
+static uint32_t default_host_threads()
 {
-    if (!b || !data || !len) return H263MI_ERR_INVALID_ARGUMENT;
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<uint32_t>(n, (uint32_t)std::max(1, CPU_COUNT(&set)));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min<uint32_t>(n, (uint32_t)std::max(1L, atol(quota) / period));
+        fclose(f);
+    }
+    return n;
+}
+
+// N x decode_next_picture.  stream_rc == nullptr: all or nothing (any stream's error fails the call, nothing changes).
+// stream_rc != nullptr: every stream is its own H263State -- a stream that fails keeps its state (state.rs:142) and gets
+// its error code, a stream without data (data[i] == nullptr) is left alone, the others advance.
+static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data, const size_t *len,
+                                      size_t *consumed, uint32_t n_threads, int *stream_rc, uint8_t strength, uint8_t *d_rgba,
+                                      uint8_t *d_deblocked)
+{
+    if (!b || !data || !len || strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
     const uint32_t n = b->n;
     for (uint32_t i = 0; i < n; i++)
-        if (!data[i] && len[i]) return H263MI_ERR_INVALID_ARGUMENT;
+        if (!data[i] && (len[i] || !stream_rc)) return H263MI_ERR_INVALID_ARGUMENT;
     if (b->parser_ctx.size() != n) b->parser_ctx.assign(n, bits::ParserContext());
     if (b->parsed.size() != n) b->parsed.resize(n);
     // The records are parsed straight into the pinned staging slot this call will copy from (stream i at i * mbs per
@@ -882,39 +1040,58 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     std::atomic<uint32_t> next{0};
     auto work = [&](unsigned) {
         for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            if (!data[i] || !b->ss[i].active) continue;          // no picture for this stream in this call
             bits::ParsedPicture &pic = b->parsed[i];
             pic.want_dense = false;                              // the coefficients travel as events
             pic.mbs_ext = g2.h_mbs + (size_t)i * per;
             pic.mbs_ext_cap = per;
-            rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
+            int rc = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
+            if (rc == H263MI_OK && (pic.desc.width != b->L.width || pic.desc.height != b->L.height)) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;
+            if (rc == H263MI_OK && !(b->ss[i].has_ref && b->ss[i].cur >= 0)) {
+                // gather.rs:149: an inter macroblock without a reference picture is Error::UncodedIFrameBlocks -- found
+                // here, before anything is queued, so that the stream (parser state included) stays as it was
+                const h263mi_mb_record *r = pic.records();
+                for (size_t k = 0, e = pic.n_records(); k < e; k++)
+                    if (mb_is_inter(r[k].mb_type)) { rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS; break; }
+                // (macroblocks the picture does not code are padded as Inter, state.rs:421-427)
+                if (rc == H263MI_OK && pic.n_records() < per) rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS;
+            }
+            rcs[i] = rc;
         }
     };
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : hw, n, 256u}));
+    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
     const auto t_parse0 = std::chrono::steady_clock::now();
     if (n_thr == 1) work(0);
     else b->workers(n_thr).run(n_thr, work);
     if (b->trace_host) b->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
-    // Any stream's error fails the call before anything is queued: the batch -- frames, reference bookkeeping and
-    // what it remembers of the picture headers -- is unchanged (state.rs:142).
-    uint8_t picture_type = H263MI_PICTURE_I;
-    bool all_disposable = true;
+    std::vector<uint8_t> takes_part(n), types(n, H263MI_PICTURE_P);
+    int first_error = H263MI_OK;
+    uint32_t n_ok = 0;
     for (uint32_t i = 0; i < n; i++) {
-        if (rcs[i] != H263MI_OK) return rcs[i];
-        const h263mi_picture_desc &d = b->parsed[i].desc;
-        if (d.width != b->L.width || d.height != b->L.height) return H263MI_ERR_PICTURE_FORMAT_INVALID;
-        if (d.picture_type != H263MI_PICTURE_I) picture_type = H263MI_PICTURE_P;
-        if (d.picture_type != H263MI_PICTURE_DISPOSABLE_P) all_disposable = false;
+        takes_part[i] = data[i] && b->ss[i].active && rcs[i] == H263MI_OK;
+        if (rcs[i] != H263MI_OK && first_error == H263MI_OK) first_error = rcs[i];
+        if (takes_part[i]) {
+            types[i] = b->parsed[i].desc.picture_type;
+            n_ok++;
+        }
+        if (stream_rc) stream_rc[i] = rcs[i];
     }
-    // Streams advance in lock step but need not agree on the picture type: the records say which macroblocks
-    // predict.  For the reference store (state.rs:464-483) the batch picture is an I picture when every stream's
-    // is, disposable when every stream's is, else a P picture.
-    if (all_disposable) picture_type = H263MI_PICTURE_DISPOSABLE_P;
+    // all or nothing: the batch -- frames, reference bookkeeping and what it remembers of the picture headers -- is
+    // unchanged (state.rs:142)
+    if (!stream_rc && first_error != H263MI_OK) return first_error;
+    if (consumed)
+        for (uint32_t i = 0; i < n; i++) consumed[i] = 0;
+    if (!n_ok) return first_error;
     std::vector<const h263mi_mb_record *> mbs(n);
     std::vector<const uint32_t *> first(n), events(n);
-    std::vector<uint32_t> n_mbs(n), n_blocks(n), n_events(n);
+    std::vector<uint32_t> n_mbs(n, 0), n_blocks(n, 0), n_events(n, 0);
+    static const uint32_t kNoEvents[1] = {0};
     for (uint32_t i = 0; i < n; i++) {
         const bits::ParsedPicture &pic = b->parsed[i];
+        mbs[i] = g2.h_mbs + (size_t)i * per;
+        first[i] = kNoEvents;
+        events[i] = nullptr;
+        if (!takes_part[i]) continue;
         mbs[i] = pic.records();
         n_mbs[i] = (uint32_t)pic.n_records();
         first[i] = pic.block_first_event.data();
@@ -922,13 +1099,42 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         n_blocks[i] = (uint32_t)pic.n_coded_blocks;
         n_events[i] = (uint32_t)pic.events.size();
     }
-    RC_TRY(batch_submit_host(b, picture_type, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
-                             n_events.data(), /*from_parser=*/true, n_thr));
+    // the streams that take part in THIS call (restored below: h263mi_batch_set_active is the caller's)
+    std::vector<uint8_t> was_active(n);
     for (uint32_t i = 0; i < n; i++) {
+        was_active[i] = b->ss[i].active;
+        b->ss[i].active = takes_part[i] != 0;
+    }
+    const bool deferred = b->pipeline_post && (d_rgba || d_deblocked);
+    int rc = batch_submit_host(b, H263MI_PICTURE_P, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
+                               n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred);
+    if (rc == H263MI_OK) {
+        if (deferred) b->note_pending(strength, d_rgba, d_deblocked);
+        else if (d_rgba || d_deblocked) rc = b->render(strength, d_rgba, d_deblocked);
+    }
+    for (uint32_t i = 0; i < n; i++) b->ss[i].active = was_active[i] != 0;
+    RC_TRY(rc);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!takes_part[i]) continue;
         b->parser_ctx[i] = b->parsed[i].next;
         if (consumed) consumed[i] = b->parsed[i].bits_consumed / 8;          // reader.commit() drains whole bytes
     }
-    return H263MI_OK;
+    return stream_rc ? H263MI_OK : first_error;
+}
+
+extern "C" {
+
+int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
+                                      const size_t *len, size_t *consumed, uint32_t n_threads)
+{
+    return batch_decode_next_pictures(b, decoder_options, data, len, consumed, n_threads, nullptr, 0, nullptr, nullptr);
+}
+
+int h263mi_batch_decode_next_pictures_ex(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
+                                         const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
+                                         uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)
+{
+    return batch_decode_next_pictures(b, decoder_options, data, len, consumed, n_threads, stream_rc, strength, d_rgba, d_deblocked);
 }
 
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)
@@ -948,8 +1154,36 @@ int h263mi_batch_sync(h263mi_batch *b)
 int h263mi_batch_reset(h263mi_batch *b)
 {
     if (!b) return H263MI_ERR_INVALID_ARGUMENT;
-    b->forget_pictures();
+    DeviceGuard g(b->device);                    // (a deferred post-processing may be launched: on the batch's device)
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    return b->forget_pictures();
+}
+
+int h263mi_batch_reset_stream(h263mi_batch *b, uint32_t stream)
+{
+    if (!b || stream >= b->n) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    return b->forget_stream(stream);
+}
+
+int h263mi_batch_set_active(h263mi_batch *b, const uint8_t *active)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < b->n; i++) b->ss[i].active = active ? active[i] != 0 : true;
     return H263MI_OK;
+}
+
+int h263mi_batch_sync_streams(h263mi_batch *b, int *stream_rc)
+{
+    if (!b) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    return b->sync(stream_rc);
+}
+
+int h263mi_batch_stream_has_picture(const h263mi_batch *b, uint32_t stream)
+{
+    return b && stream < b->n && b->ss[stream].cur >= 0 ? 1 : 0;
 }
 
 int h263mi_batch_copy_yuv(h263mi_batch *b, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr)
@@ -1037,7 +1271,10 @@ int h263mi_state_reset(h263mi_state *s)
     if (!s) return H263MI_ERR_INVALID_ARGUMENT;
     s->has_last = false;
     s->parser_ctx = bits::ParserContext();
-    if (s->b) s->b->forget_pictures();
+    if (s->b) {
+        DeviceGuard g(s->b->device);
+        return s->b->forget_pictures();
+    }
     return H263MI_OK;
 }
 
@@ -1080,7 +1317,7 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
         if (m.cbp && (size_t)m.coeff_index + (size_t)__builtin_popcount(m.cbp) > n_coeff_blocks) return H263MI_ERR_INVALID_ARGUMENT;
     }
     const bool same_size = s->b && s->b->L.width == L.width && s->b->L.height == L.height;
-    const bool has_ref = s->b && s->b->has_ref && s->b->cur >= 0;
+    const bool has_ref = s->b && s->b->ss[0].has_ref && s->b->ss[0].cur >= 0;
     if (any_inter && !has_ref) return H263MI_ERR_UNCODED_IFRAME_BLOCKS;              // gather.rs:149
     // A size change under inter prediction indexes the new planes with the reference's strides in
     // the reference (gather.rs:150,183: out-of-bounds panic or garbage); reported as an error here.
@@ -1190,7 +1427,7 @@ int h263mi_parse_picture_header(const h263mi_state *s, const uint8_t *data, size
 static int fill_view(const h263mi_state *s, h263mi_frame_view *out)
 {
     const h263mi_batch *b = s->b;
-    const uint8_t *f = b->frames[b->cur];
+    const uint8_t *f = b->frames[b->ss[0].cur];
     memset(out, 0, sizeof *out);
     out->width = (uint16_t)b->L.width;
     out->height = (uint16_t)b->L.height;
@@ -1211,7 +1448,7 @@ static int fill_view(const h263mi_state *s, h263mi_frame_view *out)
 int h263mi_get_last_picture(const h263mi_state *s, h263mi_frame_view *out)
 {
     if (!s || !out) return H263MI_ERR_INVALID_ARGUMENT;
-    if (!s->has_last || !s->b || s->b->cur < 0) return H263MI_ERR_NO_PICTURE;
+    if (!s->has_last || !s->b || s->b->ss[0].cur < 0) return H263MI_ERR_NO_PICTURE;
     return fill_view(s, out);
 }
 
@@ -1219,7 +1456,7 @@ int h263mi_get_reference_picture(const h263mi_state *s, h263mi_frame_view *out)
 {
     if (!s || !out) return H263MI_ERR_INVALID_ARGUMENT;
     // state.rs:72-78: None without a reference, otherwise the entry of *last_picture*
-    if (!s->has_last || !s->b || s->b->cur < 0 || !s->b->has_ref) return H263MI_ERR_NO_PICTURE;
+    if (!s->has_last || !s->b || s->b->ss[0].cur < 0 || !s->b->ss[0].has_ref) return H263MI_ERR_NO_PICTURE;
     return fill_view(s, out);
 }
 

@@ -94,10 +94,20 @@ inline bool layout_fits(uint64_t w, uint64_t h)
 typedef h263mi_mb_record MbRecord;
 static_assert(sizeof(MbRecord) == 32, "record layout is part of the ABI");
 
-// status bits written by kernels into a device word, read back at sync time
+// status bits written by kernels into the device word of the picture's stream, read back at sync time
 enum : uint32_t {
     STATUS_INTER_WITHOUT_REFERENCE = 1u,   // gather.rs:149 Error::UncodedIFrameBlocks
     STATUS_COEFF_INDEX_OUT_OF_RANGE = 2u,
+};
+
+// Per-stream state of a batch whose streams no longer agree (one of them was reset, skipped a call, or had a picture
+// rejected: every stream is its own H263State, state.rs:16-50).  One word per stream, read by the waves of its picture:
+enum : uint32_t {
+    STREAM_REF_SET1 = 1u,     // the stream's last picture (= its reference, state.rs:72-78) lives in frame set 1; the new one goes to the other set
+    STREAM_HAS_REF = 2u,      // reference_picture.is_some() (state.rs:29-31)
+    STREAM_RECON_SKIP = 4u,   // no picture for this stream in this call: its frames are not touched
+    STREAM_POST_SET1 = 8u,    // the picture to post-process lives in frame set 1
+    STREAM_POST_SKIP = 16u,   // nothing to post-process for this stream
 };
 
 // ---------------------------------------------------------------------------
@@ -110,7 +120,9 @@ struct ReconArgs {
     const uint64_t *coeff_base;  // per picture base (blocks) or nullptr
     const uint8_t *ref;          // reference frames (picture p at + p*frame_bytes); never null
     uint8_t *cur;                // output frames
-    uint32_t *status;            // device status word
+    uint32_t *status;            // device status words, one per picture (stream)
+    const uint32_t *stream_state;// per-stream STREAM_* words, or nullptr: every stream reads `ref`, writes `cur`, has `has_ref`
+    uint8_t *frame_set[2];       // the two frame sets (used with stream_state)
     uint64_t coeff_pool_blocks;  // size of the pool (blocks), used when coeff_checked is set
     uint32_t coeff_checked;      // 1: a coded block whose index is >= coeff_pool_blocks is an error (and is not read)
     uint32_t n_pictures;
@@ -127,6 +139,8 @@ struct ReconArgs {
 struct PostArgs {
     FrameLayout L;
     const uint8_t *frames;       // picture p at + p*frame_bytes
+    const uint32_t *stream_state;// per-stream STREAM_* words, or nullptr: every stream is read from `frames`
+    const uint8_t *frame_set[2]; // the two frame sets (used with stream_state)
     uint8_t *rgba;               // n_pictures * w*h*4, tightly packed, or nullptr
     uint8_t *planes_out;         // n_pictures * (w*h + 2*cw*ch) tightly packed deblocked planes, or nullptr
     uint32_t n_pictures;

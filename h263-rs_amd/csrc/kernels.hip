@@ -239,9 +239,20 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
 }
 
 // One wave's share of the reconstruction: the 8 macroblocks at `p`.
-__device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan)
+__device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan)
 {
-    if (p.mby >= (int)a.L.mbh) return;
+    if (p.mby >= (int)a0.L.mbh) return;
+    // A batch whose streams have drifted apart (dev_common.h: STREAM_*) says per stream where its reference lives, whether
+    // it has one, and whether it takes part in this call at all (uniform: one scalar load per wave).
+    ReconArgs a = a0;
+    if (a0.stream_state) {
+        const uint32_t st = a0.stream_state[p.pic];
+        if (st & STREAM_RECON_SKIP) return;
+        const uint32_t set = st & STREAM_REF_SET1;
+        a.ref = a0.frame_set[set];
+        a.cur = a0.frame_set[set ^ 1u];
+        a.has_ref = (st & STREAM_HAS_REF) ? 1u : 0u;
+    }
     p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;      // uniform: a scalar load
     const PrefetchTokens pf = recon_prefetch(a, plan);
 
@@ -265,7 +276,7 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a, ReconWave &s, int
     const uint64_t act64 = __ballot(ti.active != 0), inter64 = __ballot(ti.inter != 0);
     km.act = act64;                                 // bits 0..47
     km.inter = (uint32_t)(inter64 >> MB_LANE0) & 0xffu;
-    recon_report(a, ln, km.inter && !a.has_ref, __ballot(ti.bad_index != 0) != 0);
+    recon_report(a, ln, p.pic, km.inter && !a.has_ref, __ballot(ti.bad_index != 0) != 0);
     recon_phase_compact(s, ln, ti, km.act);
     wave_fence();                                   // descriptors and chroma vectors are in LDS
     const CoefRange ahead_coefs = recon_prefetch_retire(a, pf);
@@ -407,9 +418,15 @@ __device__ __forceinline__ void post_tile(const PostArgs &a, PostStrip &s, int l
 }
 
 template <bool STREAM_RGBA>
-__device__ __forceinline__ void post_wave(const PostArgs &a, PostStrip &s, int lane, int sx, int ty, int pic)
+__device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int lane, int sx, int ty, int pic)
 {
-    if (ty >= (int)a.tiles_y) return;
+    if (ty >= (int)a0.tiles_y) return;
+    PostArgs a = a0;
+    if (a0.stream_state) {                          // streams that have drifted apart (dev_common.h: STREAM_*): uniform
+        const uint32_t st = a0.stream_state[pic];
+        if (st & STREAM_POST_SKIP) return;
+        a.frames = a0.frame_set[(st & STREAM_POST_SET1) ? 1 : 0];
+    }
     if (post_tile_is_interior(a, sx, ty)) post_tile<STREAM_RGBA, true>(a, s, lane, sx, ty, pic);       // wave-uniform
     else post_tile<STREAM_RGBA, false>(a, s, lane, sx, ty, pic);
 }

@@ -440,15 +440,15 @@ H263_DEV void recon_phase_compact(ReconWave &s, int lane, const TaskInfo &t, uin
 }
 
 // status bits of the wave (wave-uniform on the device: the caller passes ballots)
-H263_DEV void recon_report(const ReconArgs &a, int lane, bool inter_without_reference, bool bad_index)
+H263_DEV void recon_report(const ReconArgs &a, int lane, int pic, bool inter_without_reference, bool bad_index)
 {
     const uint32_t bits = (inter_without_reference ? STATUS_INTER_WITHOUT_REFERENCE : 0u) |    // Error::UncodedIFrameBlocks
                           (bad_index ? STATUS_COEFF_INDEX_OUT_OF_RANGE : 0u);
     if (!bits || lane != 0) return;
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicOr(a.status, bits);
+    atomicOr(a.status + pic, bits);
 #else
-    *a.status |= bits;
+    a.status[pic] |= bits;
 #endif
 }
 

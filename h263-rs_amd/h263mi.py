@@ -63,7 +63,8 @@ EXPORTS = [
     "h263mi_get_last_picture", "h263mi_get_reference_picture", "h263mi_copy_yuv", "h263mi_render_rgba",
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
-    "h263mi_batch_decode", "h263mi_batch_decode_next_pictures",
+    "h263mi_batch_decode", "h263mi_batch_decode_next_pictures", "h263mi_batch_decode_next_pictures_ex",
+    "h263mi_batch_sync_streams", "h263mi_batch_reset_stream", "h263mi_batch_set_active", "h263mi_batch_stream_has_picture",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
     "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_timing_reserve", "h263mi_probe_bandwidth",
     "h263mi_probe_bandwidth_shape",
@@ -151,6 +152,11 @@ def lib():
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
         L.h263mi_batch_decode.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp]
         L.h263mi_batch_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32]
+        L.h263mi_batch_decode_next_pictures_ex.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp]
+        L.h263mi_batch_sync_streams.argtypes = [vp, vp]
+        L.h263mi_batch_reset_stream.argtypes = [vp, u32]
+        L.h263mi_batch_set_active.argtypes = [vp, vp]
+        L.h263mi_batch_stream_has_picture.argtypes = [vp, u32]
         L.h263mi_batch_submit_host.argtypes = [vp, u8, vp, vp, vp, vp]
         L.h263mi_batch_submit_host_events.argtypes = [vp, u8, vp, vp, vp, vp, vp, vp]
         L.h263mi_batch_render_rgba.argtypes = [vp, u8, vp, vp]
@@ -417,11 +423,41 @@ class Batch:
         return list(used)
 
     def prepare_pictures(self, data_list):
+        """(None entries: the stream has no picture in the call -- decode_next_pictures_ex only)"""
         assert len(data_list) == self.n
-        keep = [np.frombuffer(bytes(d), dtype=np.uint8) for d in data_list]
+        keep = [np.frombuffer(bytes(d), dtype=np.uint8) if d is not None else np.zeros(0, np.uint8) for d in data_list]
         pd = (C.c_void_p * self.n)(*[k.ctypes.data if k.size else None for k in keep])
         ln = (C.c_size_t * self.n)(*[k.size for k in keep])
         return pd, ln, keep
+
+    def decode_next_pictures_ex(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None,
+                                strength=0, d_rgba=None, d_deblocked=None):
+        """h263mi_batch_decode_next_pictures_ex: every stream its own H263State.  Returns (bytes consumed per stream,
+        error code per stream: 0 = decoded or no data)."""
+        pd, ln, keep = prepared if prepared is not None else self.prepare_pictures(data_list)
+        used = (C.c_size_t * self.n)()
+        rcs = (C.c_int * self.n)()
+        _check(lib().h263mi_batch_decode_next_pictures_ex(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength,
+                                                          d_rgba, d_deblocked), "batch_decode_next_pictures_ex")
+        return list(used), list(rcs)
+
+    def sync_streams(self):
+        """h263mi_batch_sync_streams: the device's verdict per stream (0 or an error code); never raises for those"""
+        rcs = (C.c_int * self.n)()
+        rc = lib().h263mi_batch_sync_streams(self._h, rcs)
+        if rc != OK and not any(rcs):
+            raise H263Error(rc, "batch_sync_streams")
+        return list(rcs)
+
+    def reset_stream(self, stream):
+        _check(lib().h263mi_batch_reset_stream(self._h, stream), "batch_reset_stream")
+
+    def set_active(self, active=None):
+        arr = None if active is None else (C.c_uint8 * self.n)(*[1 if a else 0 for a in active])
+        _check(lib().h263mi_batch_set_active(self._h, arr), "batch_set_active")
+
+    def stream_has_picture(self, stream):
+        return bool(lib().h263mi_batch_stream_has_picture(self._h, stream))
 
     def submit_host(self, picture_type, mbs_list, coeffs_list):
         """one picture per stream from host records: lists of MB_RECORD_DTYPE arrays and (n, 64) int16 arrays"""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define H263MI_ABI_VERSION 2
+#define H263MI_ABI_VERSION 3
 
 /* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
 #define H263MI_OK                                  0
@@ -283,10 +283,13 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
  * h263mi_batch_sync fail with H263MI_ERR_INVALID_ARGUMENT (0 = size unknown, nothing is checked).
  *
  * Errors the device detects (this one; an inter macroblock without a reference picture) surface at the next
- * h263mi_batch_sync.  The batch then forgets the rejected picture, as the reference leaves its state unchanged on any
- * error (state.rs:142, 464-487): if one picture was submitted since the last successful sync, the picture before
- * it is the last picture again; if several were, none survives (their frame sets have been reused) and the batch
- * is as after h263mi_batch_reset.
+ * h263mi_batch_sync, per stream (h263mi_batch_sync_streams says which).  A stream whose picture was rejected forgets
+ * it, as the reference leaves its state unchanged on any error (state.rs:142, 464-487): if one picture was submitted
+ * for it since the last successful sync, the picture before it is its last picture again; if several were, none
+ * survives (its frame sets have been reused) and the stream is as after h263mi_batch_reset_stream.  The other streams
+ * keep their pictures.
+ * Limit: a stream's coeff_index values (relative to d_coeff_base[s]) address at most 2^25 blocks (4 GiB of
+ * coefficients); a larger index is reported like one outside the pool.
  */
 int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
                         const h263mi_mb_record *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
@@ -331,9 +334,41 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  */
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads);
+/*
+ * The same with every stream treated as the H263State it is (state.rs:16-50: its own last / reference picture,
+ * its own format, its own errors):
+ *   stream_rc[s]  receives the outcome of stream s: H263MI_OK, or the error of ITS decode_next_picture -- a parse error,
+ *                 H263MI_ERR_PICTURE_FORMAT_INVALID (not the batch's size), H263MI_ERR_UNCODED_IFRAME_BLOCKS (inter
+ *                 macroblocks and no reference picture yet, gather.rs:149: found on the host, before anything is
+ *                 queued).  A stream that fails keeps its state, parser state included (state.rs:142); the others advance.
+ *   data[s] NULL  stream s has no picture in this call and is left alone (also: h263mi_batch_set_active).
+ *   d_rgba / d_deblocked (may be NULL)  deblock(strength) + BT.601 of the pictures just decoded, as h263mi_batch_decode
+ *                 does it: on a H263MI_CFG_PIPELINE_POST batch deferred to the next call's launch (k_frame), else a launch
+ *                 of its own behind the reconstruction.  Streams that did not decode a picture in this call are not
+ *                 rendered (their part of the buffers is not written).
+ * Returns H263MI_OK when the call itself went through (look at stream_rc), else a back-end error.
+ */
+int h263mi_batch_decode_next_pictures_ex(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
+                                         const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
+                                         uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_sync(h263mi_batch *b);
+/* h263mi_batch_sync with the verdict of the device per stream: stream_rc[s] = H263MI_OK,
+ * H263MI_ERR_UNCODED_IFRAME_BLOCKS or H263MI_ERR_INVALID_ARGUMENT (a coded block outside the pool).  Only the streams
+ * whose picture was rejected go back to their previous picture (or to none, when several of their pictures were in
+ * flight); the others keep theirs.  Returns the first stream's error, like h263mi_batch_sync. */
+int h263mi_batch_sync_streams(h263mi_batch *b, int *stream_rc);
+/* H263State::new for every stream again: all pictures and parser states are forgotten (a deferred post-processing is
+ * still delivered). */
 int h263mi_batch_reset(h263mi_batch *b);
+/* ... for ONE stream: the seeking rule of state.rs:134-137 applied to stream `stream` only; it then needs an I picture
+ * (its next inter macroblock is H263MI_ERR_UNCODED_IFRAME_BLOCKS) while the other streams go on predicting. */
+int h263mi_batch_reset_stream(h263mi_batch *b, uint32_t stream);
+/* Which streams take part in the following submits / decodes: active[s] != 0, or NULL = all (the default).  A stream
+ * that does not take part keeps its pictures; its records are ignored and nothing is rendered for it. */
+int h263mi_batch_set_active(h263mi_batch *b, const uint8_t *active);
+/* get_last_picture().is_some() of stream `stream` (1 / 0) */
+int h263mi_batch_stream_has_picture(const h263mi_batch *b, uint32_t stream);
 /* as_yuv of stream `stream`'s last picture -> HOST, tightly packed. */
 int h263mi_batch_copy_yuv(h263mi_batch *b, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr);
 

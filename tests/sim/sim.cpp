@@ -86,7 +86,7 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
                 if (ti[l].inter) km.inter |= 1u << (l - MB_LANE0);
                 bad_index = bad_index || ti[l].bad_index;
             }
-            for (int l = 0; l < 64; l++) recon_report(a, l, km.inter && !a.has_ref, bad_index);
+            for (int l = 0; l < 64; l++) recon_report(a, l, p.pic, km.inter && !a.has_ref, bad_index);
             for (int l = 0; l < 64; l++) recon_phase_compact(*s, l, ti[l], km.act);
             const bool mc = a.has_ref && km.inter;          // the dispatch of kernels.hip: recon_tail<MC>
             for (int l = 0; l < 64; l++) {

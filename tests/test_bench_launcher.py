@@ -30,8 +30,9 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
 
 
 def test_fewer_devices_than_requested_is_an_error_not_a_smaller_job():
-    # no stub: this container has no GPU, so 2 > visible devices
-    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    # no stub; the devices are hidden from the child, so that 2 > visible devices on a GPU box as well
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "",
+                                                               "ROCR_VISIBLE_DEVICES": ""})
     assert r.returncode != 0
     assert "device(s) visible" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -315,3 +315,139 @@ def test_bench_rccl_leg_strong_scaling_form():
     out = _bench_child(["--total-streams", "64"], {"H263MI_FORCE_DIST": "1"})
     assert out["parity_gate"] == "ok" and out["n_gpus"] == 1 and out["scaling"] == "strong"
     assert out["config"]["streams_per_gpu"] == 64 and out["config"]["pictures_per_step"] == 64 * 124
+
+
+# ---------------------------------------------------------------------------------------------
+# every stream of a batch is its own H263State (state.rs:16-50, 138-142, 464-483): one stream gets a corrupt picture and
+# keeps its state, one restarts with an I picture, one has no picture in a call, one is reset and must wait for an I
+# picture -- all 64 compared with 64 independent oracle chains after every call, through the frame-pipelined launch
+# ---------------------------------------------------------------------------------------------
+def test_batch_streams_are_independent_states():
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    w, h, n, q = 176, 144, 64, 6
+    cw = (w + 1) // 2
+    b = h263mi.Batch(n, w, h, pipeline_post=True)
+    refs = [None] * n                                            # the oracle chain of every stream
+    d_rgba = [h263mi.DeviceBuffer(n * w * h * 4) for _ in range(7)]
+    rendered = []                                                # (call, stream, expected RGBA)
+
+    def picture(s, f, intra):
+        if intra:
+            mbs, co = recgen.intra_picture(w, h, seed=1000 * f + s, max_level=60)
+            mbs = make_codable(mbs, q, s, 0)
+        else:
+            mbs, co = recgen.inter_picture(w, h, seed=1000 * f + s, mv_range=32, p_4v=0.2, p_intra=0.05, p_coded=0.4, quant=q,
+                                           max_level=60)
+            mbs = make_codable(mbs, q, s + f, 1)
+        return enc.encode_picture(w, h, 0 if intra else 1, q, mbs, co, temporal_reference=f), mbs, co
+
+    def step(f, plan, expect_rc):
+        """plan[s]: 'I', 'P', 'corrupt', None (no data).  expect_rc[s]: the code stream s must report."""
+        datas = []
+        for s in range(n):
+            kind = plan.get(s, "P")
+            if kind is None:
+                datas.append(None)
+                continue
+            data, mbs, co = picture(s, f, kind == "I")
+            if kind == "corrupt":
+                datas.append(data[:4])                           # not even a whole picture header (a picture cut off behind
+                                                                 # its header would decode: state.rs:411 ends a picture at EOF)
+                continue
+            datas.append(data)
+            if expect_rc.get(s, 0) == 0:
+                rc, refs[s] = orc.decode_picture(w, h, mbs, co, None if kind == "I" else refs[s])
+                assert rc == 0
+                rendered.append((f, s, _rgba_want(refs[s], 5, w)))
+            
+        used, rcs = b.decode_next_pictures_ex(datas, n_threads=4, strength=5, d_rgba=d_rgba[f].ptr)
+        for s in range(n):
+            want_rc = expect_rc.get(s, 0)
+            assert (rcs[s] == want_rc) if want_rc != "any error" else rcs[s] < 0, "call %d stream %d: rc %d" % (f, s, rcs[s])
+            assert (used[s] > 0) == (plan.get(s, "P") is not None and rcs[s] == 0)
+        assert all(rc == 0 for rc in b.sync_streams())
+        for s in range(n):
+            if refs[s] is None:
+                assert not b.stream_has_picture(s)
+            else:
+                assert_planes_equal(b.copy_yuv(s), refs[s], "after call %d, stream %d" % (f, s))
+
+    step(0, {s: "I" for s in range(n)}, {})
+    step(1, {}, {})
+    # stream 5: corrupt data -> its error, its state untouched; stream 9 restarts with an I picture; stream 20 sits the call out
+    step(2, {5: "corrupt", 9: "I", 20: None}, {5: "any error"})
+    step(3, {}, {})                                              # 5 and 20 predict from their picture of call 1
+    b.reset_stream(33)
+    refs[33] = None
+    assert not b.stream_has_picture(33)
+    step(4, {}, {33: h263mi.ERR_UNCODED_IFRAME_BLOCKS})          # a reset stream needs an I picture (gather.rs:149)
+    step(5, {33: "I", 40: None}, {})
+    step(6, {}, {})
+    b.sync()
+    # the RGBA of every picture that was decoded, delivered by the launch of the following call (or the last sync)
+    for f, s, want in rendered:
+        got = d_rgba[f].download(w * h * 4, s * w * h * 4)
+        assert (got == want).all(), "RGBA of call %d stream %d" % (f, s)
+    b.close()
+
+
+def test_batch_device_error_rolls_back_one_stream_only():
+    """record-level batch API: the device rejects the picture of ONE stream (a coded block outside the pool); that stream
+    goes back to its previous picture, the others keep the new one, and the next P pictures predict per stream from the
+    right frame set (the streams' ping-pong positions now differ)"""
+    w, h, n = 96, 64, 6
+    mbs_pp = 6 * 4
+    b = h263mi.Batch(n, w, h, pipeline_post=True)
+    refs = [None] * n
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+
+    def submit(f, intra, bad=None):
+        mbs_all, co_all, base, at = [], [], [], 0
+        for s in range(n):
+            m, c = (recgen.intra_picture(w, h, seed=50 * f + s) if intra else
+                    recgen.inter_picture(w, h, seed=50 * f + s, mv_range=40, p_4v=0.3, p_coded=0.5, quant=7))
+            if s == bad:
+                m = m.copy()
+                m[3]["cbp"] = 0x3F
+                m[3]["coeff_index"] = 10 ** 6                    # far outside the pool
+            else:
+                rc, refs[s] = orc.decode_picture(w, h, m, c, None if intra else refs[s])
+                assert rc == 0
+            mbs_all.append(m)
+            co_all.append(c)
+            base.append(at)
+            at += len(c)
+        d = (_upload(np.concatenate(mbs_all)), _upload(np.concatenate(co_all) if at else np.zeros((1, 64), np.int16)),
+             _upload(np.array(base, np.uint64)))
+        b.decode(h263mi.PICTURE_I if intra else h263mi.PICTURE_P, d[0].ptr, d[1].ptr, d[2].ptr, max(at, 1), 5, d_rgba.ptr)
+        return d
+
+    keep = [submit(0, True)]
+    assert all(rc == 0 for rc in b.sync_streams())
+    keep.append(submit(1, False, bad=2))
+    rcs = b.sync_streams()
+    assert rcs == [0, 0, h263mi.ERR_INVALID_ARGUMENT, 0, 0, 0]
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), refs[s], "after the rejected picture, stream %d" % s)      # refs[2] is still its I picture
+    for f in (2, 3, 4):
+        keep.append(submit(f, False))
+        assert all(rc == 0 for rc in b.sync_streams())
+        for s in range(n):
+            assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
+        got = d_rgba.download()
+        for s in range(n):
+            assert (got[s * w * h * 4:(s + 1) * w * h * 4] == _rgba_want(refs[s], 5, w)).all(), (f, s)
+    # a stream that sits calls out keeps its picture while the others advance
+    b.set_active([s != 4 for s in range(n)])
+    frozen = refs[4]
+    keep.append(submit(5, False))
+    refs[4] = frozen
+    b.sync()
+    b.set_active(None)
+    keep.append(submit(6, False))
+    b.sync()
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), refs[s], "after the skipped call, stream %d" % s)
+    b.close()
+    assert mbs_pp == len(recgen.intra_picture(w, h, seed=1)[0])

@@ -1496,67 +1496,122 @@ struct TempBuf {
     ~TempBuf() { if (p) (void)hipFree(p); }
 };
 
-int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out)
+// Device scratch of the plain-function entry points (deblock, yuv420_to_rgba): a caller in the style of Ruffle invokes
+// them once per frame, so the frame and the output buffer on the device are kept per host thread and per device and only
+// grow (round 2 paid two hipMalloc, a hipMemset and two hipFree per call).  What lies in the padding of the cached frame
+// is never used by the kernel (bytes outside the picture are loaded from clamped addresses and dropped).
+struct PlainScratch {
+    int device = -1;
+    uint8_t *frame = nullptr, *out = nullptr;
+    size_t frame_cap = 0, out_cap = 0;
+    void release()
+    {
+        if (frame) (void)hipFree(frame);
+        if (out) (void)hipFree(out);
+        frame = out = nullptr;
+        frame_cap = out_cap = 0;
+    }
+    ~PlainScratch() { release(); }
+    int reserve(int dev, size_t frame_bytes, size_t out_bytes)
+    {
+        if (dev != device) {
+            release();
+            device = dev;
+        }
+        if (frame_bytes > frame_cap) {
+            if (frame) (void)hipFree(frame);
+            frame = nullptr;
+            frame_cap = 0;
+            const size_t cap = frame_bytes + frame_bytes / 4;
+            HIP_TRY(hipMalloc((void **)&frame, cap));
+            HIP_TRY(hipMemset(frame, 0, cap));
+            frame_cap = cap;
+        }
+        if (out_bytes > out_cap) {
+            if (out) (void)hipFree(out);
+            out = nullptr;
+            out_cap = 0;
+            const size_t cap = out_bytes + out_bytes / 4;
+            HIP_TRY(hipMalloc((void **)&out, cap));
+            out_cap = cap;
+        }
+        return H263MI_OK;
+    }
+};
+static thread_local PlainScratch tls_plain;
+
+int h263mi_deblock_on(const h263mi_backend_cfg *cfg, const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out)
 {
     // preconditions of deblock.rs:30,306 (debug_asserts in the reference)
     if (!data || !out || !width || len % width != 0 || strength < 1 || strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
     const size_t height = len / width;
     if (!height || width > 65535 || height > 65535) return H263MI_ERR_INVALID_ARGUMENT;
     if (!layout_fits(width, height)) return H263MI_ERR_OUT_OF_MEMORY;          // frame offsets are 32-bit on the device
-    RC_TRY(check_device(0));
-    DeviceGuard g(0);
+    const int dev = cfg ? cfg->device_id : 0;
+    hipStream_t stream = cfg ? (hipStream_t)cfg->stream : nullptr;
+    RC_TRY(check_device(dev));
+    DeviceGuard g(dev);
     const FrameLayout L = make_layout((uint32_t)width, (uint32_t)height);
-    TempBuf frame, planes;
-    HIP_TRY(hipMalloc(&frame.p, L.frame_bytes));
-    HIP_TRY(hipMalloc(&planes.p, len));
-    HIP_TRY(hipMemset(frame.p, 0, L.frame_bytes));
-    HIP_TRY(hipMemcpy2D(frame.p, L.pitch_y, data, width, width, height, hipMemcpyHostToDevice));
+    RC_TRY(tls_plain.reserve(dev, L.frame_bytes, len));
+    HIP_TRY(hipMemcpy2DAsync(tls_plain.frame, L.pitch_y, data, width, width, height, hipMemcpyHostToDevice, stream));
     PostArgs a{};
     a.L = L;
     a.L.cwidth = a.L.cheight = 0;
-    a.frames = (const uint8_t *)frame.p;
+    a.frames = tls_plain.frame;
     a.rgba = nullptr;
-    a.planes_out = (uint8_t *)planes.p;
+    a.planes_out = tls_plain.out;
     a.n_pictures = 1;
     a.strength = strength;
     set_post_tiles(a);
     a.luma_only = 1;
-    HIP_TRY(launch_post(a, nullptr));
-    HIP_TRY(hipMemcpy(out, planes.p, len, hipMemcpyDeviceToHost));
+    HIP_TRY(launch_post(a, stream));
+    HIP_TRY(hipMemcpyAsync(out, tls_plain.out, len, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return H263MI_OK;
 }
 
-int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len, const uint8_t *chroma_b, const uint8_t *chroma_r,
-                                size_t c_len, size_t y_width, uint8_t *rgba_out)
+int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out)
+{
+    return h263mi_deblock_on(nullptr, data, len, width, strength, out);
+}
+
+int h263mi_bt601_yuv420_to_rgba_on(const h263mi_backend_cfg *cfg, const uint8_t *y, size_t y_len, const uint8_t *chroma_b,
+                                   const uint8_t *chroma_r, size_t c_len, size_t y_width, uint8_t *rgba_out)
 {
     if (y_len == 0) return H263MI_OK;                       // bt601.rs:107-112: empty in, empty out
     if (!y || !chroma_b || !chroma_r || !rgba_out || !y_width || y_len % y_width != 0) return H263MI_ERR_INVALID_ARGUMENT;
     const size_t h = y_len / y_width, cw = (y_width + 1) / 2, ch = (h + 1) / 2;   // bt601.rs:115-126
     if (c_len != cw * ch || y_width > 65535 || h > 65535) return H263MI_ERR_INVALID_ARGUMENT;
     if (!layout_fits(y_width, h)) return H263MI_ERR_OUT_OF_MEMORY;
-    RC_TRY(check_device(0));
-    DeviceGuard g(0);
+    const int dev = cfg ? cfg->device_id : 0;
+    hipStream_t stream = cfg ? (hipStream_t)cfg->stream : nullptr;
+    RC_TRY(check_device(dev));
+    DeviceGuard g(dev);
     const FrameLayout L = make_layout((uint32_t)y_width, (uint32_t)h);
-    TempBuf frame, rgba;
-    HIP_TRY(hipMalloc(&frame.p, L.frame_bytes));
-    HIP_TRY(hipMalloc(&rgba.p, y_len * 4));
-    HIP_TRY(hipMemset(frame.p, 0, L.frame_bytes));
-    uint8_t *f = (uint8_t *)frame.p;
-    HIP_TRY(hipMemcpy2D(f, L.pitch_y, y, y_width, y_width, h, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy2D(f + L.off_cb, L.pitch_c, chroma_b, cw, cw, ch, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy2D(f + L.off_cr, L.pitch_c, chroma_r, cw, cw, ch, hipMemcpyHostToDevice));
+    RC_TRY(tls_plain.reserve(dev, L.frame_bytes, y_len * 4));
+    uint8_t *f = tls_plain.frame;
+    HIP_TRY(hipMemcpy2DAsync(f, L.pitch_y, y, y_width, y_width, h, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpy2DAsync(f + L.off_cb, L.pitch_c, chroma_b, cw, cw, ch, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpy2DAsync(f + L.off_cr, L.pitch_c, chroma_r, cw, cw, ch, hipMemcpyHostToDevice, stream));
     PostArgs a{};
     a.L = L;
     a.frames = f;
-    a.rgba = (uint8_t *)rgba.p;
+    a.rgba = tls_plain.out;
     a.planes_out = nullptr;
     a.n_pictures = 1;
     a.strength = 0;
     set_post_tiles(a);
     a.luma_only = 0;
-    HIP_TRY(launch_post(a, nullptr));
-    HIP_TRY(hipMemcpy(rgba_out, rgba.p, y_len * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(launch_post(a, stream));
+    HIP_TRY(hipMemcpyAsync(rgba_out, tls_plain.out, y_len * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return H263MI_OK;
+}
+
+int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len, const uint8_t *chroma_b, const uint8_t *chroma_r,
+                                size_t c_len, size_t y_width, uint8_t *rgba_out)
+{
+    return h263mi_bt601_yuv420_to_rgba_on(nullptr, y, y_len, chroma_b, chroma_r, c_len, y_width, rgba_out);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -61,7 +61,8 @@ EXPORTS = [
     "h263mi_state_cleanup_buffers", "h263mi_submit_picture", "h263mi_decode_next_picture",
     "h263mi_parse_picture_header",
     "h263mi_get_last_picture", "h263mi_get_reference_picture", "h263mi_copy_yuv", "h263mi_render_rgba",
-    "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba",
+    "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba", "h263mi_deblock_on",
+    "h263mi_bt601_yuv420_to_rgba_on",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
     "h263mi_batch_decode", "h263mi_batch_decode_next_pictures", "h263mi_batch_decode_next_pictures_ex",
     "h263mi_batch_sync_streams", "h263mi_batch_reset_stream", "h263mi_batch_set_active", "h263mi_batch_stream_has_picture",

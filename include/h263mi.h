@@ -243,6 +243,10 @@ extern const uint8_t h263mi_quant_to_strength[32];
 /* pub fn deblock(data, width, strength) -> Vec<u8>  deblock.rs:305-315.  HOST buffers,
  * `out` holds `len` bytes; len % width == 0, 1 <= strength <= 12. */
 int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out);
+/* ... on the device and stream of `cfg` (NULL = device 0, null stream).  Both forms keep their device scratch per host
+ * thread and device between calls: a caller that invokes them once per frame allocates nothing after the first call. */
+int h263mi_deblock_on(const h263mi_backend_cfg *cfg, const uint8_t *data, size_t len, size_t width, uint8_t strength,
+                      uint8_t *out);
 
 /* ======================================================================= */
 /* yuv crate  (yuv/src/bt601.rs)                                            */
@@ -253,6 +257,9 @@ int h263mi_deblock(const uint8_t *data, size_t len, size_t width, uint8_t streng
 int h263mi_bt601_yuv420_to_rgba(const uint8_t *y, size_t y_len,
                                 const uint8_t *chroma_b, const uint8_t *chroma_r, size_t c_len,
                                 size_t y_width, uint8_t *rgba_out);
+int h263mi_bt601_yuv420_to_rgba_on(const h263mi_backend_cfg *cfg, const uint8_t *y, size_t y_len,
+                                   const uint8_t *chroma_b, const uint8_t *chroma_r, size_t c_len,
+                                   size_t y_width, uint8_t *rgba_out);
 
 /* ======================================================================= */
 /* Batch of independent streams on one GPU (no counterpart in the reference:*/

@@ -190,6 +190,7 @@ struct h263mi_batch {
     uint32_t *h_state = nullptr, *d_state = nullptr;
     hipEvent_t state_copied[kStateSlots] = {nullptr, nullptr, nullptr, nullptr};
     unsigned state_slot = 0;
+    const uint32_t *cur_first_event = nullptr, *cur_events = nullptr;   // sparse transport of the next submit (then cleared)
     uint64_t coeff_pool_blocks = 0;            // size of the pool the next submit reads ...
     bool coeff_checked = false;                // ... when the caller told us (host entry points do; device pointers do not)
     // (what sync() falls back to when the device reports an error -- state.rs:142, 464-487: an error leaves the state
@@ -378,15 +379,15 @@ struct h263mi_batch {
             g2.cap_events = cap;
         }
         RC_TRY(ensure_record_staging(g2));
-        // with sparse transport the dense blocks exist on the device only (k_expand writes them)
-        if (n_blocks > g2.cap_blocks || (!n_event_words && !g2.h_coeffs)) {
+        // with sparse transport there are no dense blocks anywhere: the reconstruction waves read the events
+        if (!n_event_words && (n_blocks > g2.cap_blocks || !g2.h_coeffs)) {
             if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
             if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
             g2.h_coeffs = nullptr; g2.d_coeffs = nullptr;
             size_t cap = std::max(n_blocks, g2.cap_blocks);
             cap = cap + cap / 2 + 64;
             g2.cap_blocks = 0;
-            if (!n_event_words) HIP_TRY(hipHostMalloc((void **)&g2.h_coeffs, cap * 128, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&g2.h_coeffs, cap * 128, hipHostMallocDefault));
             if (hipMalloc((void **)&g2.d_coeffs, cap * 128) != hipSuccess) {
                 if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
                 g2.h_coeffs = nullptr;
@@ -450,6 +451,9 @@ struct h263mi_batch {
         a.L = L;
         a.mbs = d_mbs;
         a.coeffs = d_coeffs;
+        a.block_first_event = cur_first_event;
+        a.events = cur_events;
+        cur_first_event = cur_events = nullptr;
         a.coeff_base = d_coeff_base;
         a.status = d_status;
         a.coeff_pool_blocks = coeff_pool_blocks;
@@ -733,7 +737,7 @@ struct h263mi_state {
     }
 };
 
-// n_event_words > 0: sparse transport -- the dense blocks exist on the device only (k_expand writes them)
+// n_event_words > 0: sparse transport -- no dense blocks anywhere, the reconstruction waves read the events
 static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n_blocks, size_t n_event_words)
 {
     if (n_mbs > g.cap_mbs) {
@@ -744,7 +748,7 @@ static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n
         HIP_TRY(hipMalloc((void **)&g.d_mbs, n_mbs * sizeof(MbRecord)));
         g.cap_mbs = n_mbs;
     }
-    if (n_blocks > g.cap_blocks || (!n_event_words && !g.h_coeffs)) {
+    if (!n_event_words && (n_blocks > g.cap_blocks || !g.h_coeffs)) {
         if (g.h_coeffs) (void)hipHostFree(g.h_coeffs);
         if (g.d_coeffs) (void)hipFree(g.d_coeffs);
         g.h_coeffs = nullptr; g.d_coeffs = nullptr; g.cap_blocks = 0;
@@ -954,12 +958,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     if (sparse && blocks) {
         h_first[blocks] = (uint32_t)n_ev;
         HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
-        ExpandArgs ea{};
-        ea.block_first_event = g2.d_events;
-        ea.events = g2.d_events + blocks + 1;
-        ea.coeffs = g2.d_coeffs;
-        ea.n_blocks = (uint32_t)blocks;
-        HIP_TRY(launch_expand(ea, b->stream));
+        // the reconstruction waves read the events themselves (recon_kernel.inl: coeff_row_from_events); round 2 had a
+        // kernel of its own (k_expand) rebuild dense blocks in HBM first
+        b->cur_first_event = g2.d_events;
+        b->cur_events = g2.d_events + blocks + 1;
     } else if (blocks) {
         HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
     }
@@ -1351,12 +1353,8 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
         memcpy(g2.h_events, first_event, (n_coeff_blocks + 1) * sizeof(uint32_t));
         if (n_events) memcpy(g2.h_events + n_coeff_blocks + 1, events, n_events * sizeof(uint32_t));
         HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
-        ExpandArgs ea{};
-        ea.block_first_event = g2.d_events;
-        ea.events = g2.d_events + n_coeff_blocks + 1;
-        ea.coeffs = g2.d_coeffs;
-        ea.n_blocks = (uint32_t)n_coeff_blocks;
-        HIP_TRY(launch_expand(ea, b->stream));
+        b->cur_first_event = g2.d_events;        // (read by the reconstruction waves themselves)
+        b->cur_events = g2.d_events + n_coeff_blocks + 1;
     } else if (n_coeff_blocks) {
         memcpy(g2.h_coeffs, coeffs, n_coeff_blocks * 128);
         HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, n_coeff_blocks * 128, hipMemcpyHostToDevice, b->stream));

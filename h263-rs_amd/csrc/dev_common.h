@@ -116,7 +116,9 @@ enum : uint32_t {
 struct ReconArgs {
     FrameLayout L;
     const MbRecord *mbs;         // n_pictures * mbs_per_picture records
-    const int16_t *coeffs;       // coefficient pool
+    const int16_t *coeffs;       // coefficient pool (dense transport)
+    const uint32_t *block_first_event;  // sparse transport (events != nullptr): events of coded block b of the pool are
+    const uint32_t *events;             // [block_first_event[b], block_first_event[b + 1]); level << 16 | x + 8 * y
     const uint64_t *coeff_base;  // per picture base (blocks) or nullptr
     const uint8_t *ref;          // reference frames (picture p at + p*frame_bytes); never null
     uint8_t *cur;                // output frames

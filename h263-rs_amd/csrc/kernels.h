@@ -17,15 +17,6 @@ struct SynthArgs {
     const uint64_t *coeff_base; // device, per picture
 };
 
-// sparse coefficient transport (include/h263mi.h: h263mi_submit_picture_events): events -> dense blocks
-struct ExpandArgs {
-    const uint32_t *block_first_event;   // n_blocks + 1 offsets into events
-    const uint32_t *events;              // level << 16 | raster position
-    int16_t *coeffs;                     // n_blocks * 64, every element written
-    uint32_t n_blocks;
-};
-
-hipError_t launch_expand(const ExpandArgs &args, hipStream_t stream);
 // geometry of the merged launch (k_frame), made by its launcher
 struct FrameGeom {
     uint32_t groups;            // groups of 32 luma rows per picture

@@ -2,7 +2,6 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
 #include "kernels.h"
 
-#include "expand_kernel.inl"
 #include "post_kernel.inl"
 #include "recon_kernel.inl"
 #include "synth.inl"
@@ -281,6 +280,10 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     wave_fence();                                   // descriptors and chroma vectors are in LDS
     const CoefRange ahead_coefs = recon_prefetch_retire(a, pf);
     ISA_MARK("mark_end");
+    if (recon_wave_is_static(a, km, __ballot(ti.moving != 0) != 0)) {     // eight macroblocks that are not coded and do not move
+        recon_phase_copy(a, ln, p);
+        return;
+    }
     PHASE_MARK(1);
     // Two copies of the rest, chosen per wave (uniform): waves with a prediction to fetch, and waves without one --
     // every wave of an I picture -- which issue no reference loads, compute no addresses for them and skip the
@@ -559,23 +562,6 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream)
     const uint32_t groups_y = (args.tiles_y + POST_GROUP - 1) / POST_GROUP;
     const uint32_t upp = args.tiles_x * groups_y * (POST_GROUP / POST_WAVES), chunk = (upp + 7) / 8;
     hipLaunchKernelGGL(k_post, dim3(chunk * 8, args.n_pictures), dim3(POST_THREADS), 0, stream, a);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------
-// k_expand: sparse coefficient events -> dense blocks (expand_kernel.inl)
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EXPAND_THREADS) void k_expand(ExpandArgs a)
-{
-    const uint32_t g = blockIdx.x * EXPAND_THREADS + threadIdx.x;
-    expand_lane(a.block_first_event, a.events, a.coeffs, a.n_blocks, g >> 3, (int)(g & 7));
-}
-
-hipError_t launch_expand(const ExpandArgs &args, hipStream_t stream)
-{
-    if (!args.n_blocks) return hipSuccess;
-    const uint32_t groups = (args.n_blocks * 8 + EXPAND_THREADS - 1) / EXPAND_THREADS;
-    hipLaunchKernelGGL(k_expand, dim3(groups), dim3(EXPAND_THREADS), 0, stream, args);
     return hipGetLastError();
 }
 

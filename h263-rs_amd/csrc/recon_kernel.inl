@@ -91,6 +91,7 @@ struct TaskInfo {
     uint32_t active;                           // 1: the block goes through the IDCT
     uint32_t inter;                            // 1: (macroblock lanes) inside the picture and inter coded
     uint32_t bad_index;                        // 1: coded block outside the coefficient pool
+    uint32_t moving;                           // 1: (macroblock lanes) some vector of the macroblock is not (0, 0)
 };
 H263_HD uint32_t desc_quant(uint32_t d1) { return d1 & 0xffu; }
 H263_HD uint32_t desc_level(uint32_t d1) { return (d1 >> 8) & 0x7ffu; }
@@ -416,6 +417,8 @@ H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, co
     (void)intra;
     // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
     t.inter = is_mb & valid & inter_type;
+    const uint32_t any_mv = w1 | w2 | w3 | w4;
+    t.moving = is_mb & ((any_mv | (0u - any_mv)) >> 31);                      // some vector component is not zero
 
     // gather.rs:182 / types.rs:759-768: chroma vector from the i16 sum of the four luma vectors, both components at
     // once in the two halves of a dword.  s = sum, whole = (s >> 4) << 1 = (s >> 3) & ~1, frac = s & 15,
@@ -585,7 +588,8 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
         const int slot = lane >> 3, r = lane & 7;
         f.d0 = s.desc[slot][0];                                // (garbage beyond the active tasks: never used)
         f.d1 = s.desc[slot][1];
-        f.coef0 = load16_stream(coeff_row_address(a, p, f.d0, slot < recon_n_active(km), r));
+        // (sparse transport: the first round reads its events in the load phase, like every other round)
+        f.coef0 = load16_stream(coeff_row_address(a, p, f.d0, slot < recon_n_active(km) && !a.events, r));
     }
     if (!MC) {
         f.flags = f.mvw[0] = f.mvw[1] = 0;
@@ -642,6 +646,44 @@ struct RowIn {
     bool     active;           // the lane's slot holds a block in this round
 };
 
+// Sparse transport: the coefficient row of a lane straight from the EVENTS of its block (one 32-bit word per non-zero
+// LEVEL, the form the host parser emits and the PCIe link carries) -- what k_expand used to turn into a dense pool in
+// HBM first.  The 8 lanes of a block read the same words (one cache line, broadcast) and each keeps the LEVELs of its
+// own row; a later event on a position replaces an earlier one, as in the parser's dense writer.  The loop bound is
+// the longest list among the round's 8 blocks (uniform): a handful of events for a P picture's blocks.
+H263_DEV void coeff_row_from_events(const ReconArgs &a, const WavePos &p, uint32_t d0, bool has, int r, uint32_t w[4])
+{
+    w[0] = w[1] = w[2] = w[3] = 0u;
+    uint32_t first = 0, count = 0;
+    if (has) {
+        const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
+        first = fe[0];
+        count = fe[1] - first;
+        if (count > 64u) count = 64u;                           // (a block has 64 positions)
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    while (__ballot(count != 0) != 0) {
+#else
+    while (count != 0) {
+#endif
+        // four events per trip, the addresses clamped into the list (a finished lane re-reads its last event: harmless,
+        // the same position gets the same LEVEL again)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool live = (uint32_t)j < count;
+            const uint32_t ev = has ? a.events[first + (live ? (uint32_t)j : 0u)] : 0u;
+            const uint32_t pos = ev & 63u, col = pos & 7u, level = ev >> 16, sh = 16u * (col & 1u);
+            const bool mine = live && (int)(pos >> 3) == r;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (mine && (int)(col >> 1) == k) w[k] = (w[k] & ~(0xffffu << sh)) | (level << sh);
+        }
+        const uint32_t step = count < 4u ? count : 4u;
+        first += step;
+        count -= step;
+    }
+}
+
 H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
                                     int round, RowIn &ri, const WaveMasks &km)
 {
@@ -654,10 +696,16 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     if (round > 0) {                                            // uniform
         d0 = s.desc[k % WAVE_TASKS][0];
         ri.d1 = s.desc[k % WAVE_TASKS][1];
+    }
+    const bool has = ri.active && d0 != NO_COEFFS;
+    if (a.events) {                                             // uniform
+        coeff_row_from_events(a, p, d0, has, r, ri.w);
+        return;
+    }
+    if (round > 0) {
         // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r)
         raw = load16_stream(coeff_row_address(a, p, d0, ri.active, r));
     }
-    const bool has = ri.active && d0 != NO_COEFFS;
     ri.w[0] = has ? raw.x : 0u; ri.w[1] = has ? raw.y : 0u; ri.w[2] = has ? raw.z : 0u; ri.w[3] = has ? raw.w : 0u;
 }
 
@@ -868,6 +916,32 @@ H263_DEV void recon_phase_predict(const ReconArgs &a, ReconWave &s, WaveFetch &f
 #endif
     predict_piece<LUMA_ROWS>(s, f.ly, f.mvw[0], f.flags, gl, luma_integer, all_inter);
     predict_piece<CHROMA_ROWS>(s, f.ch, f.mvw[1], f.flags >> 2, gc, chroma_integer, all_inter);
+}
+
+// ---- the short cut: eight macroblocks that are not coded and do not move ---------------------------------------
+// Most of a real P picture is COD = 1 (state.rs:207-216: Inter, zero vector, nothing coded) -- backgrounds, in runs.  A
+// wave whose eight macroblocks are all like that (uniform: nothing goes through the IDCT, every macroblock inter, every
+// vector zero) copies its 128x16 luma strip and the two 64x8 chroma strips from the reference frame to the new one, 16
+// bytes per lane and access: three loads, three stores, no prediction arithmetic (the reference's analogue is the
+// copy path of gather_block, gather.rs:63-79).
+H263_HD bool recon_wave_is_static(const ReconArgs &a, const WaveMasks &km, bool any_moving)
+{
+    return a.has_ref && km.act == 0 && km.valid == 0xffu && km.inter == 0xffu && !any_moving;
+}
+
+H263_DEV void recon_phase_copy(const ReconArgs &a, int lane, const WavePos &p)
+{
+    const uint8_t *ref = a.ref + (size_t)p.pic * a.L.frame_bytes;
+    uint8_t *cur = a.cur + (size_t)p.pic * a.L.frame_bytes;
+    const uint32_t ly = mad24((uint32_t)(p.mby * 16 + (lane >> 3)), a.L.pitch_y, (uint32_t)(p.mbx0 * 16 + (lane & 7) * 16));
+    const uint32_t ly2 = ly + 8u * a.L.pitch_y;
+    const uint32_t lc = (lane >> 5 ? a.L.off_cr : a.L.off_cb) +
+                        mad24((uint32_t)(p.mby * 8 + ((lane >> 2) & 7)), a.L.pitch_c, (uint32_t)(p.mbx0 * 8 + (lane & 3) * 16));
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(ref + ly), v1 = *reinterpret_cast<const uint4 *>(ref + ly2),
+                v2 = *reinterpret_cast<const uint4 *>(ref + lc);
+    *reinterpret_cast<uint4 *>(cur + ly) = v0;
+    *reinterpret_cast<uint4 *>(cur + ly2) = v1;
+    *reinterpret_cast<uint4 *>(cur + lc) = v2;
 }
 
 // ---- phase 6: strip -> frame ---------------------------------------------------------------

@@ -122,3 +122,42 @@ def random_planes(w, h, seed):
     cw, ch = (w + 1) // 2, (h + 1) // 2
     return (rng.integers(0, 256, w * h, dtype=np.uint8), rng.integers(0, 256, cw * ch, dtype=np.uint8),
             rng.integers(0, 256, cw * ch, dtype=np.uint8))
+
+
+def realistic_inter_picture(w, h, seed, p_skip=0.6, p_coded=0.15, quant=10, p_halfpel=0.3):
+    """A P picture shaped like real Sorenson Spark content (bench.py extra.e2e_bitstream_realistic): most macroblocks
+    are not coded at all (COD = 1: Inter, zero vector, nothing coded), the others follow one slow global motion with a
+    little jitter -- mostly integer-pel --, few blocks carry residuals, and those have two or three small low-frequency
+    coefficients.  About 3 Mbit/s at 1080p30.  Returns (mbs, coeffs)."""
+    rng = np.random.default_rng(seed)
+    mbw, mbh = mb_dims(w, h)
+    n = mbw * mbh
+    mbs = np.zeros(n, MB_RECORD_DTYPE)
+    mbs["quant"] = quant
+    gmv = rng.integers(-3, 4, 2) * 2                          # global motion, whole pixels
+    skip = rng.random(n) < p_skip
+    # skipped macroblocks come in runs (backgrounds): smooth the mask along the rows
+    skip = (np.convolve(skip.astype(np.float32), np.ones(5) / 5, mode="same") > 0.5) if n >= 5 else skip
+    coeffs = []
+    for i in range(n):
+        m = mbs[i]
+        m["coeff_index"] = len(coeffs)
+        if skip[i]:
+            continue
+        mv = gmv + rng.integers(-1, 2, 2) * 2
+        if rng.random() < p_halfpel:
+            mv = mv + rng.integers(0, 2, 2)
+        m["mv"] = np.tile(np.clip(mv, -31, 31), (4, 1))
+        cbp = 0
+        for b in range(6):
+            if rng.random() >= p_coded:
+                continue
+            cbp |= 1 << b
+            c = np.zeros(64, np.int16)
+            k = int(rng.integers(2, 4))
+            zz = rng.choice(np.arange(0, 6), k, replace=False)
+            c[ZIGZAG_RASTER[zz]] = (rng.integers(1, 4, k) * rng.choice([-1, 1], k)).astype(np.int16)
+            coeffs.append(c)
+        m["cbp"] = cbp
+    c = np.array(coeffs, np.int16).reshape(-1, 64) if coeffs else np.zeros((0, 64), np.int16)
+    return mbs, c

@@ -8,7 +8,6 @@
 #include <stdlib.h>
 
 #include "../../h263-rs_amd/csrc/post_kernel.inl"
-#include "../../h263-rs_amd/csrc/expand_kernel.inl"
 #include "../../h263-rs_amd/csrc/recon_kernel.inl"
 #include "../../h263-rs_amd/csrc/synth.inl"
 
@@ -37,14 +36,17 @@ extern "C" {
 
 void sim_layout(uint32_t w, uint32_t h, FrameLayout *out) { *out = make_layout(w, h); }
 
-int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, const int16_t *coeffs,
-              uint64_t n_blocks, const uint64_t *coeff_base, const uint8_t *ref, int has_ref, uint8_t *cur,
-              uint32_t *status)
+// block_first_event / events: sparse coefficient transport consumed by the reconstruction wave itself (nullptr: dense)
+int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, const int16_t *coeffs,
+                 uint64_t n_blocks, const uint64_t *coeff_base, const uint8_t *ref, int has_ref, uint8_t *cur,
+                 uint32_t *status, const uint32_t *block_first_event, const uint32_t *events)
 {
     ReconArgs a{};
     a.L = make_layout(w, h);
     a.mbs = mbs;
     a.coeffs = coeffs;
+    a.block_first_event = block_first_event;
+    a.events = events;
     a.coeff_base = coeff_base;
     a.ref = ref ? ref : cur;
     a.cur = cur;
@@ -88,6 +90,12 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
             }
             for (int l = 0; l < 64; l++) recon_report(a, l, p.pic, km.inter && !a.has_ref, bad_index);
             for (int l = 0; l < 64; l++) recon_phase_compact(*s, l, ti[l], km.act);
+            bool any_moving = false;
+            for (int l = 0; l < 64; l++) any_moving = any_moving || ti[l].moving;
+            if (recon_wave_is_static(a, km, any_moving)) {  // as kernels.hip::recon_wave
+                for (int l = 0; l < 64; l++) recon_phase_copy(a, l, p);
+                continue;
+            }
             const bool mc = a.has_ref && km.inter;          // the dispatch of kernels.hip: recon_tail<MC>
             for (int l = 0; l < 64; l++) {
                 if (mc) recon_phase_fetch<true>(a, *s, f[l], l, p, km);
@@ -128,6 +136,13 @@ int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, 
     }
     free(s);
     return 0;
+}
+
+int sim_recon(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, const int16_t *coeffs,
+              uint64_t n_blocks, const uint64_t *coeff_base, const uint8_t *ref, int has_ref, uint8_t *cur,
+              uint32_t *status)
+{
+    return sim_recon_ex(w, h, n_pictures, mbs, coeffs, n_blocks, coeff_base, ref, has_ref, cur, status, nullptr, nullptr);
 }
 
 int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames, uint32_t strength, uint8_t *rgba,
@@ -236,10 +251,4 @@ int sim_quartet_sweep(void (*ref)(uint8_t *, uint8_t *, uint8_t *, uint8_t *, ui
     return bad;
 }
 
-// k_expand: every (block, row) lane of the grid
-void sim_expand(const uint32_t *first, const uint32_t *events, int16_t *coeffs, uint32_t n_blocks)
-{
-    const uint32_t groups = (n_blocks * 8 + EXPAND_THREADS - 1) / EXPAND_THREADS;
-    for (uint32_t g = 0; g < groups * EXPAND_THREADS; g++) expand_lane(first, events, coeffs, n_blocks, g >> 3, (int)(g & 7));
-}
 }

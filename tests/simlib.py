@@ -30,6 +30,7 @@ def lib(asan=False):
         L.sim_layout.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(FrameLayout)]
         L.sim_recon.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sim_recon_ex.argtypes = L.sim_recon.argtypes + [C.c_void_p, C.c_void_p]
         L.sim_post.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_int]
         L.sim_synth_picture.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -77,11 +78,33 @@ def pad_records(mbs, w, h):
     return out
 
 
-def recon(w, h, mbs, coeffs, ref=None, asan=False):
-    """One picture through the kernel phases on the CPU.  Returns (status, (y, cb, cr))."""
+def recon(w, h, mbs, coeffs, ref=None, asan=False, events=False):
+    """One picture through the kernel phases on the CPU.  Returns (status, (y, cb, cr)).  events: the coefficients reach
+    the reconstruction wave as sparse events (block_first_event + events), not as dense blocks."""
     L = layout(w, h)
     mbs = pad_records(mbs, w, h)
     coeffs = np.ascontiguousarray(coeffs, np.int16).reshape(-1, 64)
+    if events:
+        # (an intra block's DC is not an event: it travels in the record)
+        intra = np.zeros(coeffs.shape[0], bool)
+        for m in mbs:
+            if int(m["mb_type"]) in (3, 4):
+                k = int(m["coeff_index"])
+                intra[k:k + bin(int(m["cbp"])).count("1")] = True
+        nz = coeffs != 0
+        nz[intra, 0] = False
+        first = np.zeros(coeffs.shape[0] + 1, np.uint32)
+        np.cumsum(nz.sum(axis=1), out=first[1:])
+        blk, pos = np.nonzero(nz)
+        ev = ((coeffs[blk, pos].astype(np.uint16).astype(np.uint32) << 16) | pos.astype(np.uint32))
+        ev = np.concatenate([ev, np.zeros(4, np.uint32)])
+        reff = pack_frame(L, ref) if ref is not None else None
+        cur = np.full(L.frame_bytes, 0xC3, np.uint8)
+        status = np.zeros(1, np.uint32)
+        dummy = np.zeros((1, 64), np.int16)
+        lib(asan).sim_recon_ex(w, h, 1, _p(mbs), _p(dummy), coeffs.shape[0], None, _p(reff), 1 if ref is not None else 0,
+                               _p(cur), _p(status), _p(first), _p(ev))
+        return int(status[0]), unpack_frame(L, cur)
     cpad = np.zeros((coeffs.shape[0] + 1, 64), np.int16)
     cpad[:coeffs.shape[0]] = coeffs
     reff = pack_frame(L, ref) if ref is not None else None

@@ -214,28 +214,31 @@ def test_quartet_arithmetic_matches_the_oracle_for_every_difference(floor_sem):
     assert bad == 0, (bad, list(first))
 
 
-def test_expand_events_rebuilds_the_dense_blocks():
-    """k_expand (sparse coefficient transport): events -> dense blocks, every byte of the pool written"""
-    import ctypes as C
-    import sys
-    sys.path.insert(0, simlib.os.path.join(simlib.HERE, "..", "h263-rs_amd"))
-    import h263mi
-    rng = np.random.default_rng(4)
-    dense = np.zeros((37, 64), np.int16)
-    for b in range(37):
-        k = int(rng.integers(0, 65)) if b % 5 else 0           # some blocks without any event
-        pos = rng.choice(64, size=k, replace=False)
-        lv = rng.integers(-1023, 1024, size=k)
-        lv[lv == 0] = 7
-        dense[b, pos] = lv
-    first, ev = h263mi.events_from_dense(dense)
-    out = np.full((37, 64), 0x5A5A, np.int16)
-    L = simlib.lib()
-    L.sim_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
-    L.sim_expand.restype = None
-    evp = ev if ev.size else np.zeros(1, np.uint32)
-    L.sim_expand(first.ctypes.data, evp.ctypes.data, out.ctypes.data, 37)
-    assert (out == dense).all()
+def test_events_later_entry_on_a_position_replaces_the_earlier_one():
+    """sparse coefficient transport: a later event on a position replaces an earlier one (as the parser's dense writer
+    does); checked through the reconstruction wave's own event reader"""
+    w, h = 16, 16
+    mbs = np.zeros(1, orc.MB_RECORD_DTYPE)
+    mbs["quant"] = 4
+    mbs["cbp"] = 1
+    ref = recgen.random_planes(w, h, 3)
+    dense = np.zeros((1, 64), np.int16)
+    dense[0, 9] = -5
+    dense[0, 2] = 7
+    rc, want = orc.decode_picture(w, h, mbs, dense, ref)
+    L = simlib.layout(w, h)
+    first = np.array([0, 4], np.uint32)
+    ev = np.array([(3 << 16) | 9, (7 << 16) | 2, ((-5) & 0xffff) << 16 | 9, (7 << 16) | 2, 0, 0, 0, 0], np.uint32)
+    cur = np.full(L.frame_bytes, 0xC3, np.uint8)
+    status = np.zeros(1, np.uint32)
+    dummy = np.zeros((1, 64), np.int16)
+    padded = simlib.pad_records(mbs, w, h)
+    simlib.lib().sim_recon_ex(w, h, 1, simlib._p(padded), simlib._p(dummy), 1, None, simlib._p(simlib.pack_frame(L, ref)), 1,
+                              simlib._p(cur), simlib._p(status), simlib._p(first), simlib._p(ev))
+    got = simlib.unpack_frame(L, cur)
+    assert rc == 0 and status[0] == 0
+    for g, e in zip(got, want):
+        assert (g == e).all()
 
 
 def test_kernel_phases_on_the_mutation_sensitive_blocks():
@@ -255,3 +258,47 @@ def test_kernel_phases_on_the_mutation_sensitive_blocks():
     assert (got[0].reshape(h, w) == np.clip(want, 0, 255)).all()
     rc, oracle_planes = orc.decode_picture(w, h, inter, coeffs, flat)
     assert rc == 0 and (oracle_planes[0] == got[0]).all()
+
+
+@pytest.mark.parametrize("w,h", [(176, 144), (100, 60), (48, 32), (16, 16)])
+def test_recon_from_events_equals_recon_from_dense_blocks(w, h):
+    """sparse coefficient transport consumed by the reconstruction wave itself (recon_kernel.inl: coeff_row_from_events):
+    same pictures as from dense blocks -- intra pictures with every block class (dense blocks = 63 events), P pictures
+    with sparse residuals, mixed intra / inter"""
+    mbs, coeffs = recgen.intra_picture(w, h, seed=w + 7 * h)
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, None)
+    st, got = simlib.recon(w, h, mbs, coeffs, None, events=True)
+    assert rc == 0 and st == 0
+    for g, e, name in zip(got, want, "Y Cb Cr".split()):
+        assert (g == e).all(), ("intra", name, np.flatnonzero(g != e)[:10])
+    ref = want
+    for seed in (1, 2):
+        mbs, coeffs = recgen.inter_picture(w, h, seed=seed * 91 + w, mv_range=50, p_4v=0.3, p_intra=0.2, p_coded=0.5, quant=0,
+                                           max_level=127, sparse_low=seed == 1)
+        rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+        st, got = simlib.recon(w, h, mbs, coeffs, ref, events=True)
+        assert rc == 0 and st == 0
+        for g, e, name in zip(got, want, "Y Cb Cr".split()):
+            assert (g == e).all(), ("inter", seed, name, np.flatnonzero(g != e)[:10])
+        ref = want
+
+
+@pytest.mark.parametrize("w,h", [(256, 48), (176, 144), (384, 32)])
+def test_recon_static_waves_take_the_copy_path(w, h):
+    """pictures shaped like real content (tests/recgen.py: realistic_inter_picture): runs of macroblocks that are not
+    coded and do not move -- whole waves of them take recon_phase_copy -- beside moving and coded ones, and the all-static
+    picture (every wave copies)"""
+    ref = recgen.random_planes(w, h, 11)
+    for seed in (1, 2, 3):
+        mbs, coeffs = recgen.realistic_inter_picture(w, h, seed, p_skip=0.8 if seed == 3 else 0.6)
+        rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+        st, got = simlib.recon(w, h, mbs, coeffs, ref)
+        assert rc == 0 and st == 0
+        for g, e, name in zip(got, want, "Y Cb Cr".split()):
+            assert (g == e).all(), (seed, name, np.flatnonzero(g != e)[:10])
+    mbs = np.zeros(((w + 15) // 16) * ((h + 15) // 16), orc.MB_RECORD_DTYPE)
+    mbs["quant"] = 5
+    st, got = simlib.recon(w, h, mbs, np.zeros((0, 64), np.int16), ref)
+    assert st == 0
+    for g, e in zip(got, ref):
+        assert (g == e).all()

@@ -932,8 +932,19 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                 uint32_t *fo = h_first + g2.h_base[i];
                 bool ascending = true;
                 for (uint32_t k = 0; k < n_coeff_blocks[i]; k++) {
-                    ascending = ascending && first_event[i][k] <= first_event[i][k + 1];
+                    ascending = ascending && first_event[i][k] <= first_event[i][k + 1] && first_event[i][k + 1] <= n_events[i];
                     fo[k] = first_event[i][k] + ev_base[i];
+                }
+                // a caller's events: at most 64 per block, every position once (the device places them in no particular order)
+                for (uint32_t k = 0; k < n_coeff_blocks[i] && ascending && !from_parser; k++) {
+                    uint64_t seen = 0;
+                    const uint32_t e0 = first_event[i][k], e1 = first_event[i][k + 1];
+                    if (e1 - e0 > 64) ascending = false;
+                    for (uint32_t e = e0; e < e1 && ascending; e++) {
+                        const uint64_t bit = 1ull << (events[i][e] & 63u);
+                        if (seen & bit) ascending = false;
+                        seen |= bit;
+                    }
                 }
                 if (!ascending) offsets_ok.store(false, std::memory_order_relaxed);
                 if (n_events[i]) memcpy(h_ev + ev_base[i], events[i], (size_t)n_events[i] * sizeof(uint32_t));
@@ -1299,8 +1310,17 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
     if (sparse && n_coeff_blocks) {
         // offsets must be monotone and end at n_events: checked here, the kernel trusts them
         if (first_event[0] != 0 || first_event[n_coeff_blocks] != n_events) return H263MI_ERR_INVALID_ARGUMENT;
-        for (size_t i = 0; i < n_coeff_blocks; i++)
-            if (first_event[i] > first_event[i + 1]) return H263MI_ERR_INVALID_ARGUMENT;
+        // ... and a block's events name every position at most once (the device places them in no particular order)
+        for (size_t i = 0; i < n_coeff_blocks; i++) {
+            if (first_event[i] > first_event[i + 1] || first_event[i + 1] > n_events || first_event[i + 1] - first_event[i] > 64)
+                return H263MI_ERR_INVALID_ARGUMENT;
+            uint64_t seen = 0;
+            for (uint32_t e = first_event[i]; e < first_event[i + 1]; e++) {
+                const uint64_t bit = 1ull << (events[e] & 63u);
+                if (seen & bit) return H263MI_ERR_INVALID_ARGUMENT;
+                seen |= bit;
+            }
+        }
     }
     if (!desc->width || !desc->height || !layout_fits(desc->width, desc->height)) return H263MI_ERR_PICTURE_FORMAT_INVALID;
     if (desc->picture_type > H263MI_PICTURE_RESERVED) return H263MI_ERR_INVALID_ARGUMENT;

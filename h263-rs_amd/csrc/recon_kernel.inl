@@ -646,46 +646,55 @@ struct RowIn {
     bool     active;           // the lane's slot holds a block in this round
 };
 
-// Sparse transport: the coefficient row of a lane straight from the EVENTS of its block (one 32-bit word per non-zero
-// LEVEL, the form the host parser emits and the PCIe link carries) -- what k_expand used to turn into a dense pool in
-// HBM first.  The 8 lanes of a block read the same words (one cache line, broadcast) and each keeps the LEVELs of its
-// own row; a later event on a position replaces an earlier one, as in the parser's dense writer.  The loop bound is
-// the longest list among the round's 8 blocks (uniform): a handful of events for a P picture's blocks.
-H263_DEV void coeff_row_from_events(const ReconArgs &a, const WavePos &p, uint32_t d0, bool has, int r, uint32_t w[4])
+// Sparse transport: the coefficient rows of a round straight from the EVENTS of its 8 blocks (one 32-bit word per
+// non-zero LEVEL, the form the host parser emits and the PCIe link carries) -- what k_expand used to turn into a dense
+// pool in HBM first.  The round's 8 x 64 LEVELs are rebuilt in LDS (1 KB, in the space the row pass writes its results
+// to afterwards: every lane has read its row before any lane of the wave gets there): the buffer is zeroed, the 8 lanes
+// of a block take the block's events eight at a time (lane r the events r, r + 8, ...: one coalesced 32-byte read per
+// block and trip) and drop each LEVEL at its position, then every lane reads back its row.  The trip count is that of
+// the longest list among the 8 blocks (uniform): one trip for the blocks of a P picture, eight for a dense block.
+// The positions of a block's events must be distinct (every entry point that takes events from a caller checks it; the
+// parser emits each position at most once).
+// `stage`: -1 = the three steps one after the other (the device: the wave's lanes run in lock step and the fences order
+// the steps); 0, 1, 2 = one step only (the CPU logic checker runs the lanes one after the other and therefore each step
+// over all lanes before the next).
+H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const WavePos &p, uint32_t d0, bool has, int lane,
+                                     uint32_t w[4], int stage = -1)
 {
-    w[0] = w[1] = w[2] = w[3] = 0u;
-    uint32_t first = 0, count = 0;
-    if (has) {
-        const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
-        first = fe[0];
-        count = fe[1] - first;
-        if (count > 64u) count = 64u;                           // (a block has 64 positions)
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    while (__ballot(count != 0) != 0) {
-#else
-    while (count != 0) {
-#endif
-        // four events per trip, the addresses clamped into the list (a finished lane re-reads its last event: harmless,
-        // the same position gets the same LEVEL again)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool live = (uint32_t)j < count;
-            const uint32_t ev = has ? a.events[first + (live ? (uint32_t)j : 0u)] : 0u;
-            const uint32_t pos = ev & 63u, col = pos & 7u, level = ev >> 16, sh = 16u * (col & 1u);
-            const bool mine = live && (int)(pos >> 3) == r;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (mine && (int)(col >> 1) == k) w[k] = (w[k] & ~(0xffffu << sh)) | (level << sh);
+    const int slot = lane >> 3, r = lane & 7;
+    int16_t *dense = reinterpret_cast<int16_t *>(s.tbuf);       // [8 slots][64 positions]
+    if (stage < 0 || stage == 0) *reinterpret_cast<uint4 *>(dense + lane * 8) = make_uint4(0, 0, 0, 0);
+    if (stage < 0 || stage == 1) {
+        uint32_t at = 0, end = 0;
+        if (has) {
+            const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
+            const uint32_t first = fe[0], count = fe[1] - first;
+            at = first + (uint32_t)r;
+            end = first + (count > 64u ? 64u : count);          // (a block has 64 positions)
         }
-        const uint32_t step = count < 4u ? count : 4u;
-        first += step;
-        count -= step;
+        wave_fence();                                           // zeroed before the first LEVEL lands
+#if defined(__HIP_DEVICE_COMPILE__)
+        while (__ballot(at < end) != 0) {
+#else
+        while (at < end) {
+#endif
+            if (at < end) {
+                const uint32_t ev = a.events[at];
+                dense[slot * 64 + (int)(ev & 63u)] = (int16_t)(ev >> 16);
+            }
+            at += 8u;
+        }
+        wave_fence();                                           // all LEVELs of the round are in place
+    }
+    if (stage < 0 || stage == 2) {
+        const uint4 row = *reinterpret_cast<const uint4 *>(dense + slot * 64 + r * 8);
+        w[0] = row.x; w[1] = row.y; w[2] = row.z; w[3] = row.w;
+        wave_fence();                                           // (the row pass overwrites this space: reads first)
     }
 }
 
 H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
-                                    int round, RowIn &ri, const WaveMasks &km)
+                                    int round, RowIn &ri, const WaveMasks &km, int events_stage = -1)
 {
     const int slot = lane >> 3, r = lane & 7;
     const int k = round * ROUND_BLOCKS + slot;
@@ -699,7 +708,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     }
     const bool has = ri.active && d0 != NO_COEFFS;
     if (a.events) {                                             // uniform
-        coeff_row_from_events(a, p, d0, has, r, ri.w);
+        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, events_stage);
         return;
     }
     if (round > 0) {

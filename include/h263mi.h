@@ -182,8 +182,10 @@ int h263mi_submit_picture(h263mi_state *s, const h263mi_picture_desc *desc,
  * event per non-zero LEVEL, `(uint16_t)level << 16 | position` with position = x + 8*y (the de-zigzagged place,
  * DEZIGZAG_MAPPING rle.rs:6-71; an intra block's DC is not an event, it travels in the record).  Coded block k
  * (the numbering of coeff_index) owns events [block_first_event[k], block_first_event[k+1]); the array has
- * n_coeff_blocks + 1 entries, starts at 0 and ends at n_events.  A typical P picture needs a quarter of the
- * bytes of the dense form over PCIe; a small kernel rebuilds the dense blocks in device memory.
+ * n_coeff_blocks + 1 entries, starts at 0 and ends at n_events; a block has at most 64 events and names every position
+ * at most once (checked: H263MI_ERR_INVALID_ARGUMENT).  A typical P picture needs a quarter of the bytes of the dense
+ * form over PCIe, and the reconstruction waves read the events as they are: no dense block is ever built in device
+ * memory.
  */
 #define H263MI_EVENT(position, level) (((uint32_t)(uint16_t)(int16_t)(level) << 16) | ((uint32_t)(position) & 63u))
 int h263mi_submit_picture_events(h263mi_state *s, const h263mi_picture_desc *desc,

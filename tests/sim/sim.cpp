@@ -110,10 +110,10 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
                 uint64_t rows_any = 0, cols_any = 0;
                 bool any_special = false;
                 if (n_active > 0) {
-                    for (int l = 0; l < 64; l++) {
-                        recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l], km);
-                        wm |= rowin_word_mask(ri[l]);
-                    }
+                    // (sparse transport: the three steps of coeff_rows_from_events each over all lanes)
+                    for (int stage = a.events ? 0 : 2; stage < 3; stage++)
+                        for (int l = 0; l < 64; l++) recon_phase_idct_load(a, *s, f[l], l, p, round, ri[l], km, a.events ? stage : -1);
+                    for (int l = 0; l < 64; l++) wm |= rowin_word_mask(ri[l]);
                     for (int l = 0; l < 64; l++) {
                         const RowClass rc = recon_row_class(ri[l], l);
                         if (rc.any) { rows_any |= 1ull << l; rm |= 1u << (l & 7); }

@@ -214,33 +214,6 @@ def test_quartet_arithmetic_matches_the_oracle_for_every_difference(floor_sem):
     assert bad == 0, (bad, list(first))
 
 
-def test_events_later_entry_on_a_position_replaces_the_earlier_one():
-    """sparse coefficient transport: a later event on a position replaces an earlier one (as the parser's dense writer
-    does); checked through the reconstruction wave's own event reader"""
-    w, h = 16, 16
-    mbs = np.zeros(1, orc.MB_RECORD_DTYPE)
-    mbs["quant"] = 4
-    mbs["cbp"] = 1
-    ref = recgen.random_planes(w, h, 3)
-    dense = np.zeros((1, 64), np.int16)
-    dense[0, 9] = -5
-    dense[0, 2] = 7
-    rc, want = orc.decode_picture(w, h, mbs, dense, ref)
-    L = simlib.layout(w, h)
-    first = np.array([0, 4], np.uint32)
-    ev = np.array([(3 << 16) | 9, (7 << 16) | 2, ((-5) & 0xffff) << 16 | 9, (7 << 16) | 2, 0, 0, 0, 0], np.uint32)
-    cur = np.full(L.frame_bytes, 0xC3, np.uint8)
-    status = np.zeros(1, np.uint32)
-    dummy = np.zeros((1, 64), np.int16)
-    padded = simlib.pad_records(mbs, w, h)
-    simlib.lib().sim_recon_ex(w, h, 1, simlib._p(padded), simlib._p(dummy), 1, None, simlib._p(simlib.pack_frame(L, ref)), 1,
-                              simlib._p(cur), simlib._p(status), simlib._p(first), simlib._p(ev))
-    got = simlib.unpack_frame(L, cur)
-    assert rc == 0 and status[0] == 0
-    for g, e in zip(got, want):
-        assert (g == e).all()
-
-
 def test_kernel_phases_on_the_mutation_sensitive_blocks():
     """the committed blocks on which a fused or re-associated IDCT changes a pixel (tests/golden/
     idct_sensitive_blocks.json) through the kernel phase functions on the CPU: same pixels as the reference arithmetic"""

@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip extra.e2e_bitstream (it encodes test streams in Python: ~15 s)")
     ap.add_argument("--no-parity-gate", action="store_true", help="profiling runs only: the line then says so")
+    ap.add_argument("--dense-coeffs", action="store_true",
+                    help="coefficients as dense 128-byte blocks in HBM (h263mi_batch_decode) instead of the sparse events the "
+                         "host parser emits (h263mi_batch_decode_events)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="two launches per frame index (k_recon, then k_post) instead of the frame-pipelined single launch")
     ap.add_argument("--overlap", action="store_true",
@@ -111,9 +114,9 @@ def launch_ranks(args, argv):
 class Workload:
     """Device-resident records of `gop` frame indices for `n` streams."""
 
-    def __init__(self, h263mi, n, gop, first_stream, device_id, stream, i_kind=None, p_frames=True):
+    def __init__(self, h263mi, n, gop, first_stream, device_id, stream, i_kind=None, p_frames=True, events=False):
         i_kind = h263mi.SYNTH_I_MIXED if i_kind is None else i_kind
-        self.n, self.frames, self.h263mi = n, [], h263mi
+        self.n, self.frames, self.h263mi, self.events = n, [], h263mi, events
         for f in range(gop):
             kind = i_kind if (f == 0 or not p_frames) else h263mi.SYNTH_P
             cap = n * MBS_PP * (6 if kind != h263mi.SYNTH_P else 2)
@@ -123,7 +126,42 @@ class Workload:
             blocks = h263mi.synth_batch_device(kind, W, H, n, first_stream, f, d_mbs.ptr, d_co.ptr, cap, d_base.ptr,
                                                device_id, stream)
             ptype = h263mi.PICTURE_I if kind != h263mi.SYNTH_P else h263mi.PICTURE_P
-            self.frames.append(dict(kind=kind, ptype=ptype, mbs=d_mbs, co=d_co, base=d_base, blocks=blocks))
+            fr = dict(kind=kind, ptype=ptype, mbs=d_mbs, co=d_co, base=d_base, blocks=blocks)
+            if events:
+                fr.update(self.to_events(fr, device_id))
+            self.frames.append(fr)
+
+    def to_events(self, fr, device_id):
+        """The same coefficients as sparse events (h263mi_submit_picture_events: one 32-bit word per non-zero LEVEL, an
+        intra block's DC stays in its record), the transport form of the host parser: converted once, on the host, from
+        the dense pool the generator wrote; the dense pool is freed."""
+        import numpy as np
+        h263mi, n = self.h263mi, self.n
+        h263mi.synchronize(device_id)
+        rec = fr["mbs"].download(n * MBS_PP * 32).view(h263mi.MB_RECORD_DTYPE)
+        base = fr["base"].download(n * 8).view(np.uint64)
+        blocks = fr["blocks"]
+        co = fr["co"].download(blocks * 128).view(np.int16).reshape(-1, 64)
+        cbp = rec["cbp"].astype(np.uint32)
+        npop = np.zeros(len(rec), np.int64)
+        for b in range(6):
+            npop += (cbp >> b) & 1
+        pool_index = np.repeat(base.astype(np.int64), MBS_PP) + rec["coeff_index"].astype(np.int64)
+        intra_mb = (rec["mb_type"] == 3) | (rec["mb_type"] == 4)
+        sel = intra_mb & (npop > 0)
+        starts, lens = pool_index[sel], npop[sel]
+        intra_block = np.zeros(blocks, bool)
+        if lens.size:
+            within = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
+            intra_block[np.repeat(starts, lens) + within] = True
+        first, ev = h263mi.events_from_dense(co, intra_block)
+        ev = np.concatenate([ev, np.zeros(8, np.uint32)])
+        d_first = h263mi.DeviceBuffer(first.nbytes, device_id)
+        d_first.upload(first)
+        d_ev = h263mi.DeviceBuffer(ev.nbytes, device_id)
+        d_ev.upload(ev)
+        fr["co"].free()
+        return dict(co=None, first=d_first, ev=d_ev, n_events=int(first[-1]))
 
     def recon_bytes(self, f):
         """algorithmic bytes of one k_recon launch: headers + coefficients + reference read
@@ -152,7 +190,10 @@ def run_frames(batch, wl, d_rgba, n_frames, pipeline=False):
     g = len(wl.frames)
     for i in range(n_frames):
         fr = wl.frames[i % g]
-        if pipeline:
+        if pipeline and wl.events:
+            batch.decode_events(fr["ptype"], fr["mbs"].ptr, fr["first"].ptr, fr["ev"].ptr, fr["base"].ptr, 0, STRENGTH,
+                                d_rgba.ptr, None)
+        elif pipeline:
             batch.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, 0, STRENGTH, d_rgba.ptr, None)
         else:
             batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
@@ -467,8 +508,9 @@ def main(argv=None):
         raise SystemExit("--total-streams %d is not a multiple of %d GPUs" % (args.total_streams, world))
     n = args.total_streams // world if strong else args.streams
     my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU; strong: total / GPUs
-    wl = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream)
     pipeline = not args.no_pipeline and not args.overlap
+    use_events = pipeline and not args.dense_coeffs
+    wl = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream, events=use_events)
     batch = h263mi.Batch(n, W, H, local_rank, stream, overlap_post=args.overlap, pipeline_post=pipeline)
     d_rgba = h263mi.DeviceBuffer(n * RGBA_BYTES, local_rank)
     frames_per_step = args.gop * args.gops_per_step
@@ -572,6 +614,27 @@ def main(argv=None):
                 "k_recon_p_alg_bytes_per_launch": int(recon_alg_p)}
 
     extra = {}
+    if rank == 0 and world == 1 and not args.no_extra and use_events:
+        # the same workload with the coefficients as dense 128-byte blocks in HBM (round 1-2's transport)
+        wld = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream, events=False)
+        run_frames(batch, wld, d_rgba, args.gop, pipeline)
+        batch.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_frames(batch, wld, d_rgba, 2 * frames_per_step, pipeline)
+        batch.sync()
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t1
+        extra["dense_coefficient_transport"] = {
+            "ms_per_frame_index": round(dtd / (2 * frames_per_step) * 1e3, 4),
+            "mp_per_s": round(n * 2 * frames_per_step * MP_PER_PICTURE / dtd, 1),
+            "what": "the same pictures with h263mi_batch_decode: coefficients as dense int16[64] blocks in HBM (%.0f MB per "
+                    "P frame index) instead of events (%.1f MB)" % (wld.frames[1]["blocks"] * 128 / 1e6,
+                                                                    wl.frames[1]["n_events"] * 4 / 1e6)}
+        for fr in wld.frames:
+            for k in ("mbs", "co", "base"):
+                fr[k].free()
+        del wld
     if rank == 0 and world == 1 and not args.no_extra:
         # BASELINE configs[1]: dense 1080p I pictures (every block Full): dequant + IDCT + YUV->RGBA, no deblock
         del wl
@@ -628,8 +691,11 @@ def main(argv=None):
                                "over the resident input = %d GOPs x %d frame indices = %d pictures per stream (%d per "
                                "step and GPU); GOP = 1 I (mixed block classes) + %d P (half-pel MVs in [-32,31], 25%% "
                                "coded blocks, quant 10); dequant+IDCT+MC+add/clip, deblock strength %d, BT.601 RGBA; "
-                               "records pre-generated in HBM" % (n, args.gops_per_step, args.gop, frames_per_step,
-                                                                 n * frames_per_step, args.gop - 1, STRENGTH),
+                               "records pre-generated in HBM, coefficients %s" % (
+                                   n, args.gops_per_step, args.gop, frames_per_step, n * frames_per_step, args.gop - 1, STRENGTH,
+                                   "as sparse events (one 32-bit word per non-zero LEVEL: the host parser's transport form, "
+                                   "h263mi_batch_decode_events)" if use_events else "as dense int16[64] blocks (h263mi_batch_decode)"),
+                   "coefficient_transport": "events" if use_events else "dense",
                    "streams_per_gpu": n, "width": W, "height": H, "gop": args.gop, "gops_per_step": args.gops_per_step,
                    "pictures_per_step": n * frames_per_step * world,
                    "parallelism": "streams sharded per GPU, no data-path collective"},

@@ -857,6 +857,28 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
     return b->render(strength, d_rgba, d_deblocked);
 }
 
+/* the same with the coefficients as sparse events already in device memory (what the host entry points copy there) */
+int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
+                               const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
+                               uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)
+{
+    if (!b || !d_mbs || !d_block_first_event || !d_events || picture_type > H263MI_PICTURE_RESERVED || strength > 12)
+        return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(b->device);
+    b->coeff_checked = coeff_pool_blocks != 0;
+    b->coeff_pool_blocks = coeff_pool_blocks;
+    b->cur_first_event = d_block_first_event;
+    b->cur_events = d_events;
+    if (b->pipeline_post) {
+        RC_TRY(b->submit(picture_type, d_mbs, nullptr, d_coeff_base, /*with_post=*/b->pending.valid));
+        b->note_pending(strength, d_rgba, d_deblocked);
+        return H263MI_OK;
+    }
+    RC_TRY(b->submit(picture_type, d_mbs, nullptr, d_coeff_base));
+    if (!d_rgba && !d_deblocked) return H263MI_OK;
+    return b->render(strength, d_rgba, d_deblocked);
+}
+
 }  // extern "C"
 
 // one picture per stream from per-stream host arrays; coefficients dense (`coeffs`) or as events (`first_event`,

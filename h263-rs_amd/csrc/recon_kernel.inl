@@ -588,8 +588,15 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
         const int slot = lane >> 3, r = lane & 7;
         f.d0 = s.desc[slot][0];                                // (garbage beyond the active tasks: never used)
         f.d1 = s.desc[slot][1];
-        // (sparse transport: the first round reads its events in the load phase, like every other round)
-        f.coef0 = load16_stream(coeff_row_address(a, p, f.d0, slot < recon_n_active(km) && !a.events, r));
+        if (a.events) {
+            // sparse transport: where the events of the lane's block start and end (the two words are requested here, with
+            // everything else the wave loads; the events themselves follow in the first round's load phase)
+            const bool has = slot < recon_n_active(km) && f.d0 != NO_COEFFS;
+            const uint32_t *fe = has ? a.block_first_event + (p.cbase + (f.d0 >> 7)) : reinterpret_cast<const uint32_t *>(a.mbs);
+            f.coef0 = make_uint4(fe[0], fe[1], 0u, 0u);
+        } else {
+            f.coef0 = load16_stream(coeff_row_address(a, p, f.d0, slot < recon_n_active(km), r));
+        }
     }
     if (!MC) {
         f.flags = f.mvw[0] = f.mvw[1] = 0;
@@ -659,7 +666,8 @@ struct RowIn {
 // the steps); 0, 1, 2 = one step only (the CPU logic checker runs the lanes one after the other and therefore each step
 // over all lanes before the next).
 H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const WavePos &p, uint32_t d0, bool has, int lane,
-                                     uint32_t w[4], int stage = -1)
+                                     uint32_t w[4], int stage = -1, bool bounds_known = false, uint32_t known_first = 0,
+                                     uint32_t known_next = 0)
 {
     const int slot = lane >> 3, r = lane & 7;
     int16_t *dense = reinterpret_cast<int16_t *>(s.tbuf);       // [8 slots][64 positions]
@@ -668,7 +676,8 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
         uint32_t at = 0, end = 0;
         if (has) {
             const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
-            const uint32_t first = fe[0], count = fe[1] - first;
+            // (the first round's bounds were requested by the fetch phase)
+            const uint32_t first = bounds_known ? known_first : fe[0], count = (bounds_known ? known_next : fe[1]) - first;
             at = first + (uint32_t)r;
             end = first + (count > 64u ? 64u : count);          // (a block has 64 positions)
         }
@@ -708,7 +717,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     }
     const bool has = ri.active && d0 != NO_COEFFS;
     if (a.events) {                                             // uniform
-        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, events_stage);
+        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, events_stage, round == 0, raw.x, raw.y);
         return;
     }
     if (round > 0) {

@@ -64,7 +64,7 @@ EXPORTS = [
     "h263mi_quant_to_strength", "h263mi_deblock", "h263mi_bt601_yuv420_to_rgba", "h263mi_deblock_on",
     "h263mi_bt601_yuv420_to_rgba_on",
     "h263mi_batch_create", "h263mi_batch_destroy", "h263mi_batch_mbs_per_picture", "h263mi_batch_submit",
-    "h263mi_batch_decode", "h263mi_batch_decode_next_pictures", "h263mi_batch_decode_next_pictures_ex",
+    "h263mi_batch_decode", "h263mi_batch_decode_events", "h263mi_batch_decode_next_pictures", "h263mi_batch_decode_next_pictures_ex",
     "h263mi_batch_sync_streams", "h263mi_batch_reset_stream", "h263mi_batch_set_active", "h263mi_batch_stream_has_picture",
     "h263mi_batch_render_rgba", "h263mi_batch_sync", "h263mi_batch_reset", "h263mi_batch_copy_yuv",
     "h263mi_batch_timing_begin", "h263mi_batch_timing_end", "h263mi_batch_timing_reserve", "h263mi_probe_bandwidth",
@@ -152,6 +152,7 @@ def lib():
         L.h263mi_batch_mbs_per_picture.restype = u32
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
         L.h263mi_batch_decode.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp]
+        L.h263mi_batch_decode_events.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, u8, vp, vp]
         L.h263mi_batch_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32]
         L.h263mi_batch_decode_next_pictures_ex.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp]
         L.h263mi_batch_sync_streams.argtypes = [vp, vp]
@@ -349,6 +350,10 @@ class H263State:
         return out
 
 
+def synchronize(device_id=0):
+    _check(lib().h263mi_device_synchronize(device_id), "device_synchronize")
+
+
 class DeviceBuffer:
     def __init__(self, nbytes, device_id=0):
         self.device_id, self.nbytes = device_id, nbytes
@@ -413,6 +418,12 @@ class Batch:
         """submit + render_rgba in one call (h263mi_batch_decode)"""
         _check(lib().h263mi_batch_decode(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength,
                                          d_rgba, d_deblocked), "batch_decode")
+
+    def decode_events(self, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base=None, coeff_pool_blocks=0,
+                      strength=0, d_rgba=None, d_deblocked=None):
+        """h263mi_batch_decode_events: decode with the coefficients as sparse events in device memory"""
+        _check(lib().h263mi_batch_decode_events(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
+                                                coeff_pool_blocks, strength, d_rgba, d_deblocked), "batch_decode_events")
 
     def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None):
         """one coded picture per stream (bytes-like objects) through the host parser threads and the GPU; returns the

@@ -303,6 +303,15 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
 int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
                         const h263mi_mb_record *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
                         uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
+/* h263mi_batch_decode with sparse coefficient transport (see h263mi_submit_picture_events), everything in DEVICE memory:
+ * d_block_first_event[k], [k + 1] bound the events of coded block k of the pool (k = d_coeff_base[s] + the stream's own
+ * block number; the array has one entry more than the pool has blocks), d_events holds `level << 16 | x + 8 * y` per
+ * non-zero LEVEL (an intra block's DC travels in the record), at most 64 per block, every position at most once.  This
+ * is the form the host parser emits and h263mi_batch_decode_next_pictures copies to the device: the reconstruction
+ * waves read it as it is. */
+int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
+                               const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
+                               uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
 /* deblock (strength 0 = off) + BT.601 of every stream's last picture into d_rgba
  * (DEVICE, n_streams * w*h*4 bytes, stream-major); d_deblocked (DEVICE, may be NULL)
  * additionally receives the filtered planes, n_streams * (w*h + 2*cw*ch) bytes as

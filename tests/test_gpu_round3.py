@@ -451,3 +451,55 @@ def test_batch_device_error_rolls_back_one_stream_only():
         assert_planes_equal(b.copy_yuv(s), refs[s], "after the skipped call, stream %d" % s)
     b.close()
     assert mbs_pp == len(recgen.intra_picture(w, h, seed=1)[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# h263mi_batch_decode_events: records + sparse events in device memory (the transport form of the host parser), read
+# by the reconstruction waves as they are -- intra pictures of every block class (up to 63 events per block), P pictures
+# with sparse and with full residuals, through k_recon and through the frame-pipelined launch
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,n,pipeline", [(176, 144, 3, False), (100, 60, 17, True), (352, 288, 2, True)])
+def test_batch_decode_events_matches_the_oracle(w, h, n, pipeline):
+    b = h263mi.Batch(n, w, h, pipeline_post=pipeline)
+    refs = [None] * n
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+    keep = []
+    for f in range(5):
+        intra = f in (0, 3)
+        mbs_all, co_all, intra_blocks, base, at = [], [], [], [], 0
+        for s in range(n):
+            if intra:
+                m, c = recgen.intra_picture(w, h, seed=31 * s + f)
+            else:
+                m, c = recgen.inter_picture(w, h, seed=200 * f + s, mv_range=40, p_4v=0.3, p_intra=0.15, p_coded=0.5, quant=0,
+                                            max_level=127, sparse_low=bool(s & 1))
+            rc, refs[s] = orc.decode_picture(w, h, m, c, None if intra else refs[s])
+            assert rc == 0
+            m = simlib_pad(m, w, h)
+            blk_intra = np.zeros(len(c), bool)
+            for r in m:
+                if int(r["mb_type"]) in (3, 4):
+                    k = int(r["coeff_index"])
+                    blk_intra[k:k + bin(int(r["cbp"])).count("1")] = True
+            mbs_all.append(m)
+            co_all.append(c)
+            intra_blocks.append(blk_intra)
+            base.append(at)
+            at += len(c)
+        first, ev = h263mi.events_from_dense(np.concatenate(co_all) if at else np.zeros((0, 64), np.int16),
+                                             np.concatenate(intra_blocks) if at else None)
+        ev = np.concatenate([ev, np.zeros(8, np.uint32)])
+        d = (_upload(np.concatenate(mbs_all)), _upload(first), _upload(ev), _upload(np.array(base, np.uint64)))
+        keep.append(d)
+        b.decode_events(h263mi.PICTURE_I if intra else h263mi.PICTURE_P, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, max(at, 1), 5,
+                        d_rgba.ptr)
+        b.sync()
+        for s in range(n):
+            assert_planes_equal(b.copy_yuv(s), refs[s], "frame %d stream %d" % (f, s))
+            assert (d_rgba.download(w * h * 4, s * w * h * 4) == _rgba_want(refs[s], 5, w)).all(), (f, s)
+    b.close()
+
+
+def simlib_pad(mbs, w, h):
+    import simlib
+    return simlib.pad_records(mbs, w, h)

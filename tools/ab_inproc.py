@@ -21,6 +21,7 @@ import h263mi  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--gops", type=int, default=3)
+ap.add_argument("--dense-coeffs", action="store_true", help="dense coefficient blocks instead of events")
 ap.add_argument("--placements", type=int, default=1, help="allocate the input / output buffers this many times over and run the A/B on each")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
@@ -44,10 +45,12 @@ def time_gops(b, w, n_frames, rgba, strength=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     g = len(w.frames)
-    for i in range(n_frames):
-        fr = w.frames[i % g]
-        b.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, 0, bench.STRENGTH if strength is None else strength,
-                 rgba.ptr, None)
+    if strength is None:
+        bench.run_frames(b, w, rgba, n_frames, True)
+    else:
+        for i in range(n_frames):
+            fr = w.frames[i % g]
+            b.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, 0, strength, rgba.ptr, None)
     b.sync()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n_frames * 1e3
@@ -56,7 +59,7 @@ def time_gops(b, w, n_frames, rgba, strength=None):
 spacers = []
 for placement in range(args.placements):
     h263mi._lib = handles[0]
-    wl = bench.Workload(h263mi, N, GOP, 0, 0, stream)
+    wl = bench.Workload(h263mi, N, GOP, 0, 0, stream, events=not args.dense_coeffs)
     dense = bench.Workload(h263mi, N, 1, 0, 0, stream, i_kind=h263mi.SYNTH_I_DENSE, p_frames=False)
     rgba = h263mi.DeviceBuffer(N * bench.RGBA_BYTES, 0)
     res = [[] for _ in handles]
@@ -80,8 +83,9 @@ for placement in range(args.placements):
     rgba.free()
     for w in (wl, dense):
         for fr in w.frames:
-            for key in ("mbs", "co", "base"):
-                fr[key].free()
+            for key in ("mbs", "co", "base", "first", "ev"):
+                if fr.get(key) is not None:
+                    fr[key].free()
     spacers.append(h263mi.DeviceBuffer(((placement * 41) % 89 + 5) << 20, 0))
 for L, b in zip(handles, batches):
     h263mi._lib = L

@@ -156,6 +156,11 @@ class Workload:
             intra_block[np.repeat(starts, lens) + within] = True
         first, ev = h263mi.events_from_dense(co, intra_block)
         ev = np.concatenate([ev, np.zeros(8, np.uint32)])
+        # The transport is chosen per picture: events pay off for sparse blocks (a P picture's 4 LEVELs per block); a
+        # picture that averages more than 8 events per coded block (the GOP's I picture) stays dense -- rebuilding its
+        # blocks from events takes the reconstruction waves eight trips per round.
+        if int(first[-1]) > 8 * max(blocks, 1):
+            return dict(first=None, ev=None, n_events=int(first[-1]))
         d_first = h263mi.DeviceBuffer(first.nbytes, device_id)
         d_first.upload(first)
         d_ev = h263mi.DeviceBuffer(ev.nbytes, device_id)
@@ -190,7 +195,7 @@ def run_frames(batch, wl, d_rgba, n_frames, pipeline=False):
     g = len(wl.frames)
     for i in range(n_frames):
         fr = wl.frames[i % g]
-        if pipeline and wl.events:
+        if pipeline and wl.events and fr.get("first") is not None:
             batch.decode_events(fr["ptype"], fr["mbs"].ptr, fr["first"].ptr, fr["ev"].ptr, fr["base"].ptr, 0, STRENGTH,
                                 d_rgba.ptr, None)
         elif pipeline:
@@ -694,7 +699,7 @@ def main(argv=None):
                                "records pre-generated in HBM, coefficients %s" % (
                                    n, args.gops_per_step, args.gop, frames_per_step, n * frames_per_step, args.gop - 1, STRENGTH,
                                    "as sparse events (one 32-bit word per non-zero LEVEL: the host parser's transport form, "
-                                   "h263mi_batch_decode_events)" if use_events else "as dense int16[64] blocks (h263mi_batch_decode)"),
+                                   "h263mi_batch_decode_events) for the P pictures, dense blocks for the GOP's I picture" if use_events else "as dense int16[64] blocks (h263mi_batch_decode)"),
                    "coefficient_transport": "events" if use_events else "dense",
                    "streams_per_gpu": n, "width": W, "height": H, "gop": args.gop, "gops_per_step": args.gops_per_step,
                    "pictures_per_step": n * frames_per_step * world,

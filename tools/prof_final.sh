@@ -19,7 +19,7 @@ STAMP="box: $(grep 'BEST copy' $OUT/box.txt | awk '{print $3" GB/s copy ceiling"
 echo "$STAMP" >> $OUT/box.txt
 echo "== $STAMP"
 # ---- kernel trace of the default bench command
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 # ---- HBM traffic: two counter-only passes
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_$C.log

@@ -23,9 +23,12 @@ ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--gops", type=int, default=3)
 ap.add_argument("--dense-coeffs", action="store_true", help="dense coefficient blocks instead of events")
 ap.add_argument("--placements", type=int, default=1, help="allocate the input / output buffers this many times over and run the A/B on each")
+ap.add_argument("--strength", type=int, default=None, help="deblocking strength of the P workload (default: the bench's; 0 = no deblocking)")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 
+if args.strength is not None:
+    bench.STRENGTH = args.strength
 torch.cuda.set_device(0)
 stream = torch.cuda.current_stream().cuda_stream
 N, GOP = 64, bench.GOP

@@ -486,10 +486,6 @@ H263_DEV void store16_align4(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c, u
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
     const u32x4 v = {a, b, c, d};
-#if defined(H263MI_EXP_RGBA_STORE_MODE)
-    // experiment: the cache-policy bits of the RGBA stores (gfx940+: sc0 / sc1 = scope, nt = non-temporal)
-    if (STREAM) { asm volatile("global_store_dwordx4 %0, %1, off " H263MI_EXP_RGBA_STORE_MODE :: "v"(dst), "v"(v) : "memory"); return; }
-#endif
     if (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a4 *>(dst));
     else *reinterpret_cast<u32x4_a4 *>(dst) = v;
 #else

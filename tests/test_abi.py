@@ -137,3 +137,16 @@ def test_oversized_pictures_are_rejected_before_any_allocation():
     assert L.h263mi_batch_create(1, 1920, 1080, C.byref(cfg), C.byref(out)) in (h263mi.OK, h263mi.ERR_NO_DEVICE)
     if out:
         L.h263mi_batch_destroy(out)
+
+
+def test_committed_traffic_figure_belongs_to_the_kernel_sources_in_the_tree():
+    """bench.py reports roofline.traffic from profiles/traffic_latest.json only when that file was measured on the
+    kernel sources in the tree (a hash over csrc/*.inl, *.hip, *.h): editing a kernel without re-running
+    tools/prof_final.sh would silently turn the figure into null on the driver's bench line."""
+    import json
+    import bench
+    tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    assert tr["kernel_source_hash"] == bench.kernel_source_hash(), \
+        "profiles/traffic_latest.json is from other kernel code: re-run tools/prof_final.sh and copy its traffic.json"
+    k = tr["kernels"]["k_frame"]
+    assert k["launches_sampled"] >= 60 and 0.9e9 < k["hbm_bytes_per_launch"] < 1.3e9

@@ -21,6 +21,90 @@ class FuzzMismatch(AssertionError):
     pass
 
 
+def _dev(arr):
+    arr = np.ascontiguousarray(arr)
+    d = h263mi.DeviceBuffer(max(arr.nbytes, 16))
+    if arr.nbytes:
+        d.upload(arr)
+    return d
+
+
+def fuzz_batch(rng, w, h, seed, n_pic, n_px):
+    import simlib
+    n = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24]))
+    pipeline, events = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    frames = int(rng.integers(2, 6))
+    b = h263mi.Batch(n, w, h, pipeline_post=pipeline)
+    d_rgba = [h263mi.DeviceBuffer(n * w * h * 4) for _ in range(frames)]
+    refs, keep, want = [None] * n, [], []
+    cw = (w + 1) // 2
+    what = (w, h, n, pipeline, events, seed)
+    for f in range(frames):
+        intra = f == 0 or rng.random() < 0.2
+        mbs_all, co_all, blk_intra_all, base, at = [], [], [], [], 0
+        for s_ in range(n):
+            sd = int(rng.integers(0, 1 << 30))
+            if intra:
+                m, c = recgen.intra_picture(w, h, seed=sd, max_level=int(rng.choice([40, 127, 1023])))
+            else:
+                m, c = recgen.inter_picture(w, h, seed=sd, mv_range=int(rng.choice([2, 32, 70])), p_4v=float(rng.choice([0.0, 0.3])),
+                                            p_intra=float(rng.choice([0.0, 0.15])), p_coded=float(rng.choice([0.05, 0.3, 0.9])),
+                                            quant=int(rng.choice([0, 1, 10, 31])), max_level=int(rng.choice([3, 60, 1023])),
+                                            sparse_low=bool(rng.integers(0, 2)))
+            rc, refs[s_] = orc.decode_picture(w, h, m, c, None if intra else refs[s_])
+            assert rc == 0
+            m = simlib.pad_records(m, w, h)
+            bi = np.zeros(len(c), bool)
+            for r in m:
+                if int(r["mb_type"]) in (3, 4):
+                    k = int(r["coeff_index"])
+                    bi[k:k + bin(int(r["cbp"])).count("1")] = True
+            mbs_all.append(m)
+            co_all.append(c)
+            blk_intra_all.append(bi)
+            base.append(at)
+            at += len(c)
+        co = np.concatenate(co_all) if at else np.zeros((0, 64), np.int16)
+        strength = int(rng.integers(0, 13))
+        pt = h263mi.PICTURE_I if intra else h263mi.PICTURE_P
+        d_m, d_b = _dev(np.concatenate(mbs_all)), _dev(np.array(base, np.uint64))
+        if events:
+            first, ev = h263mi.events_from_dense(co, np.concatenate(blk_intra_all) if at else None)
+            d_f, d_e = _dev(first), _dev(np.concatenate([ev, np.zeros(8, np.uint32)]))
+            keep.append((d_m, d_b, d_f, d_e))
+            b.decode_events(pt, d_m.ptr, d_f.ptr, d_e.ptr, d_b.ptr, max(at, 1), strength, d_rgba[f].ptr)
+        else:
+            d_c = _dev(co if at else np.zeros((1, 64), np.int16))
+            keep.append((d_m, d_b, d_c))
+            b.decode(pt, d_m.ptr, d_c.ptr, d_b.ptr, max(at, 1), strength, d_rgba[f].ptr)
+        # a pipelined batch renders picture f inside the launch that reconstructs picture f + 1 -- unless a sync comes
+        # first, which renders it with a launch of its own: both orders occur
+        if rng.random() < 0.3:
+            b.sync()
+        want.append([])
+        for s_ in range(n):
+            planes = refs[s_] if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(refs[s_], (w, cw, cw)))
+            want[f].append(orc.yuv420_to_rgba(*planes, w))
+        n_pic += n
+        n_px += n * w * h
+    b.sync()
+    for f in range(frames):
+        for s_ in range(n):
+            if not (d_rgba[f].download(w * h * 4, s_ * w * h * 4) == want[f][s_]).all():
+                raise FuzzMismatch("batch rgba: %r frame %d stream %d" % (what, f, s_))
+    for s_ in sorted(set([0, n - 1, int(rng.integers(0, n))])):
+        for g, e, name in zip(b.copy_yuv(s_), refs[s_], "Y Cb Cr".split()):
+            if not (np.asarray(g) == e).all():
+                raise FuzzMismatch("batch planes: %r stream %d %s" % (what, s_, name))
+    b.close()
+    for d in d_rgba:
+        d.free()
+    for t in keep:
+        for d in t:
+            d.free()
+    return n_pic, n_px
+
+
 def run(budget=60.0, seed=1, verbose=True):
     """random pictures for `budget` seconds; returns (pictures, pixels); raises FuzzMismatch on the first difference"""
     rng = np.random.default_rng(seed)
@@ -34,6 +118,12 @@ def run(budget=60.0, seed=1, verbose=True):
                             rng.integers(260, 800), 4 * rng.integers(65, 200)]))
         h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288,
                             rng.integers(64, 420), 4 * rng.integers(16, 100)]))
+        if rng.random() < 0.2:
+            # a BATCH of streams in lock step (h263mi_batch_decode / _decode_events), plain or frame-pipelined: the launch
+            # that the bench times, at random sizes, stream counts, transports and filter strengths; RGBA of every
+            # picture of every stream, planes of a few
+            n_pic, n_px = fuzz_batch(rng, min(w, 400), min(h, 300), seed, n_pic, n_px)
+            continue
         if rng.random() < 0.35:
             # through the bitstream: records -> test encoder -> h263mi_decode_next_picture (host parser, sparse transport)
             standard = bool(rng.integers(0, 2))

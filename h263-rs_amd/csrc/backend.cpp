@@ -1001,6 +1001,9 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     b->coeff_pool_blocks = blocks;
     b->coeff_checked = true;
     RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types));
+    // (timing: the bracket ends right behind the launch -- closed at the next call it would hold the time the device
+    // idles while the host parses the next pictures)
+    RC_TRY(b->time_close());
     HIP_TRY(hipEventRecord(g2.done, b->stream));
     b->host_slot++;
     if (b->trace_host) {

@@ -835,7 +835,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         int mb_type = 0, cb = 0, cr = 0, luma = 0, dquant = 0;
         bool has_dquant = false;
         Mv mvd[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        bool have_header = false;
+        bool have_header = false, run_taken = false;
         if (window_header && r.remaining() >= 64) do {
             const size_t avail = r.remaining();
             uint64_t w = r.peek_window();
@@ -843,7 +843,30 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             const auto top32 = [&]() { return (uint32_t)((w << used) >> 32); };
             if (is_p) {
                 used = 1;
-                if (w >> 63) { uncoded = true; r.advance(1); have_header = true; break; }
+                if (w >> 63) {
+                    // COD = 1.  Real P pictures are mostly runs of these (60-70 % of the macroblocks): the whole run of
+                    // one bits at the top of the window is taken at once -- as many as the picture still has room for; a
+                    // macroblock beyond that goes the ordinary way and is reported there.  Each is Macroblock::Uncoded
+                    // (state.rs:207-216): an INTER record with zero vectors in the zero-initialised array.
+                    const size_t room = total > n_mbs ? total - n_mbs : 0;
+                    size_t run = (size_t)__builtin_clzll(~w | 1ull);           // leading ones, 1..63
+                    if (run > room) run = room;
+                    if (run >= 2) {
+                        const uint8_t q = (uint8_t)(in_force_quantizer < 1 ? 1 : in_force_quantizer);
+                        for (size_t k = 0; k < run; k++) {
+                            recs[n_mbs + k].mb_type = H263MI_MB_INTER;
+                            recs[n_mbs + k].quant = q;
+                        }
+                        memset(pv + n_mbs * 4, 0, run * 4 * sizeof(Mv));
+                        n_mbs += run;
+                        mb_col += run;
+                        while (mb_col >= mb_per_line) { mb_col -= mb_per_line; mb_line++; }
+                        r.advance((uint32_t)run);
+                        run_taken = true;
+                        break;
+                    }
+                    uncoded = true; r.advance(1); have_header = true; break;
+                }
             }
             const VlcTable::Slot &m = t_mcbpc.lookup32(top32());
             if (!m.valid) break;
@@ -883,6 +906,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             r.advance(used);
             have_header = true;
         } while (0);
+        if (run_taken) continue;
         if (!have_header) {
             stuffing = uncoded = has_dquant = false;
             do {                                     // decode_macroblock (macroblock.rs:445-549)

@@ -24,6 +24,11 @@ def _streams():
         out.append(("P stuffing %dx%d" % (w, h), enc.encode_picture(w, h, 1, 9, mbs, co, stuffing_every=3), 1))
         first = int(np.flatnonzero(mbs["cbp"] & 1)[0])
         out.append(("P overflow %dx%d" % (w, h), enc.encode_picture(w, h, 1, 9, mbs, co, overflow_blocks={(first, 0)}), 1))
+    # real content: runs of COD = 1 macroblocks (taken a run at a time out of the header window), short and longer than
+    # the window, across macroblock rows, to the last macroblock of the picture; and a picture of nothing else
+    for w, h, seed, p_skip in ((176, 144, 41, 0.7), (352, 288, 42, 0.9), (100, 60, 43, 0.5), (352, 288, 44, 1.0)):
+        mbs, co = recgen.realistic_inter_picture(w, h, seed, p_skip=p_skip, p_coded=0.0 if p_skip == 1.0 else 0.15)
+        out.append(("P skips %.1f %dx%d" % (p_skip, w, h), enc.encode_picture(w, h, 1, 9, make_codable(mbs, 9, seed, 1), co), 1))
     # standard H.263 (no Sorenson escape width flag, resynchronisation after macroblock header errors)
     mbs, co = recgen.inter_picture(176, 144, seed=31, mv_range=30, p_4v=0.2, p_intra=0.1, p_coded=0.4, quant=8, max_level=100,
                                    sparse_low=False)
@@ -115,3 +120,18 @@ def test_a_macroblock_too_many_is_noticed_without_writing_behind_the_slot():
             assert diff == 0 and used, (name, skip, diff, rc)
             seen.add(rc)
     assert -12 in seen
+
+
+def test_ones_behind_the_last_macroblock_are_a_macroblock_too_many_in_both_forms():
+    """a picture whose data runs on in one bits: the run of COD = 1 macroblocks stops at the picture's last macroblock,
+    the next one is reported (the reference indexes out of bounds there), nothing is written behind the caller's slot"""
+    for name, data, options in STREAMS:
+        if not name.startswith("P skips"):
+            continue
+        w, h = [int(v) for v in name.split()[-1].split("x")]
+        per = ((w + 15) // 16) * ((h + 15) // 16)
+        for tail in (b"\xff", b"\xff" * 9, b"\xff" * 40):
+            diff, rc, used = pl.compare_record_destinations(data + tail, per, options)
+            assert diff == 0 and used, (name, len(tail), diff, rc)
+            diff, rc = pl.compare_parser_paths(data + tail, options)
+            assert diff == 0, (name, len(tail), diff, rc)

@@ -161,3 +161,37 @@ def realistic_inter_picture(w, h, seed, p_skip=0.6, p_coded=0.15, quant=10, p_ha
         m["cbp"] = cbp
     c = np.array(coeffs, np.int16).reshape(-1, 64) if coeffs else np.zeros((0, 64), np.int16)
     return mbs, c
+
+
+def realistic_intra_picture(w, h, seed, quant=10, p_coded=0.7):
+    """An I picture shaped like real content at a moderate quantiser (the key frame of bench.py's
+    extra.e2e_bitstream_realistic): every block has its INTRADC, 70 % of the blocks carry one to six small
+    low-frequency coefficients (two on average), none has a dense spectrum.  About 110 KB at 1080p, against the 2.3 MB of
+    the mixed-class test picture.  Returns (mbs, coeffs)."""
+    rng = np.random.default_rng(seed)
+    mbw, mbh = mb_dims(w, h)
+    n = mbw * mbh
+    mbs = np.zeros(n, MB_RECORD_DTYPE)
+    mbs["mb_type"] = INTRA
+    mbs["quant"] = quant
+    # INTRADC: a smooth field plus a little texture, kept inside the legal codes 1..254 without 128
+    gy, gx = np.divmod(np.arange(n), mbw)
+    field = 128 + 70 * np.sin(gx / 9.0 + seed) * np.cos(gy / 7.0) + rng.normal(0, 6, n)
+    dc = np.clip(field[:, None] + rng.normal(0, 4, (n, 6)), 1, 254).astype(np.int64)
+    dc[dc == 128] = 129
+    dc[:, 4:] = np.clip(128 + (dc[:, 4:] - 128) // 4, 1, 254)
+    dc[dc == 128] = 127
+    mbs["intradc"] = dc.astype(np.uint8)
+    coded = rng.random((n, 6)) < p_coded
+    mbs["cbp"] = (coded * (1 << np.arange(6))).sum(axis=1).astype(np.uint8)
+    n_blocks = int(coded.sum())
+    counts = coded.sum(axis=1)
+    mbs["coeff_index"] = (np.cumsum(counts) - counts).astype(np.uint32)
+    co = np.zeros((n_blocks, 64), np.int16)
+    k = np.minimum(rng.geometric(0.5, n_blocks), 6)
+    for j in range(6):
+        sel = np.flatnonzero(k > j)
+        zz = rng.integers(1, 11, sel.size)                        # zigzag 1..10 (0 is the DC, carried by INTRADC)
+        lv = (rng.integers(1, 4, sel.size) * rng.choice([-1, 1], sel.size)).astype(np.int16)
+        co[sel, ZIGZAG_RASTER[zz]] = lv
+    return mbs, co

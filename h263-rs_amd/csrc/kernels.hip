@@ -191,7 +191,7 @@ __device__ __forceinline__ void recon_round_cols(ReconWave &s, int lane, const R
 {
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    recon_phase_idct_cols(s, rs.ri, ln, rows_from_mask(rs.rows_mask), rs.rows_any, rs.cols_any, rs.any_special);
+    recon_phase_idct_cols(s, rs.ri, ln, rows_from_mask(rs.rows_mask), rs.rows_any, rs.cols_any, rs.any_special, /*strip_is_zero=*/!MC);
     ISA_MARK2(MC, "mc_", "intra_", "idct_cols_end");
 }
 

@@ -222,6 +222,20 @@ typedef float f32x2 __attribute__((vector_size(8)));
 #define H263_CONST_TABLE static const
 #endif
 H263_CONST_TABLE float kBasis[8][8] = {H263MI_BASIS_ROWS};    // idct.rs:39-48
+// The same table times 0.25, for the column pass.  idct.rs:189 divides the result of the second pass by 4.0 before it
+// rounds; a power of two commutes with every IEEE rounding on the way (no product or partial sum comes anywhere near
+// the subnormal range: the smallest non-zero one is ~0.19 * 0.19 / 4), so sum(in[f] * (B[f][i] / 4)) IS sum(in[f] *
+// B[f][i]) / 4, bit for bit, and the multiplication by 0.25 costs nothing.
+struct BasisQuarter {
+    float v[8][8];
+    constexpr BasisQuarter() : v{}
+    {
+        constexpr float b[8][8] = {H263MI_BASIS_ROWS};
+        for (int f = 0; f < 8; f++)
+            for (int i = 0; i < 8; i++) v[f][i] = b[f][i] * 0.25f;
+    }
+};
+H263_CONST_TABLE BasisQuarter kBasisQuarter = BasisQuarter();
 
 H263_DEV f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
 // four consecutive floats (16-byte aligned) in one store
@@ -250,6 +264,16 @@ H263_DEV BasisPtr basis_table()
     return b;
 #else
     return kBasis;
+#endif
+}
+H263_DEV BasisPtr basis_table_quarter()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    BasisPtr b = (BasisPtr)kBasisQuarter.v;
+    asm volatile("" : "+s"(b));
+    return b;
+#else
+    return kBasisQuarter.v;
 #endif
 }
 H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], B[f][2 * ip + 1]}; return r; }
@@ -790,8 +814,10 @@ H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
 // rows_any / cols_any: bit slot*8 + r set when coefficient row r of the slot's block holds a non-zero value /
 // one in a column x > 0 (ballots of RowClass on the device).  A block is Horiz when no row r > 0 holds anything,
 // Vert when no row holds anything beyond column 0, Dc (or Zero) when both (rle.rs:138-171).
+// strip_is_zero: no macroblock of the wave takes a prediction (an all-intra wave): the strip holds zeros wherever a
+// block of the wave is about to be written, so the residual is the pixel and the read + add of the strip are left out.
 H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int n_rows, uint64_t rows_any, uint64_t cols_any,
-                                    bool any_special)
+                                    bool any_special, bool strip_is_zero = false)
 {
     if (!ri.active) return;
     const int slot = lane >> 3, i = lane & 7;
@@ -809,16 +835,18 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
 #pragma unroll
     for (int r = 0; r < 8; r++) col[r] = r < n_rows ? src[r * TBUF_ROW] : 0.0f;       // uniform: rows >= n_rows are zero
 
+    // O = a QUARTER of the second pass's result (basis table times 0.25, see kBasisQuarter): what idct.rs:189 rounds
     f32x2 O[4];
-    const BasisPtr B = basis_table();
-    idct_1d_pairs(B, col, O, n_rows);
+    const BasisPtr B4 = basis_table_quarter();
+    idct_1d_pairs(B4, col, O, n_rows);
     if (any_special) {                                             // uniform: some block of the round is Vert, Dc or Zero
         // class fix-ups as one multiply and one add (both exact where they must not change the value):
         //   Vert: x * B[0][0] (idct.rs:160)          others: x * 1.0
         //   Dc  : x * 0 + dc * 0.5 (idct.rs:119: exactly 0.5, not B00*B00; dc = 0 gives the Zero class)
+        // on quarters: (x / 4) * B00 = (x * B00) / 4 and dc * 0.125 = (dc * 0.5) / 4, exactly
         const float c00 = col[0];
-        const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? B[0][0] : 1.0f));
-        const f32x2 shift = splat2(dc_class ? c00 * 0.5f : 0.0f);
+        const f32x2 scale = splat2(dc_class ? 0.0f : (vert ? B4[0][0] * 4.0f : 1.0f));
+        const f32x2 shift = splat2(dc_class ? c00 * 0.125f : 0.0f);
 #pragma unroll
         for (int jp = 0; jp < 4; jp++) O[jp] = O[jp] * scale + shift;
     }
@@ -831,13 +859,12 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
     uint8_t *base = &s.pix[task_pix_origin(t) + i];
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) {
-        const f32x2 o = O[jp];
-        const f32x2 q4 = o * splat2(0.25f);
+        const f32x2 q4 = O[jp];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const float v = q4[h] + __builtin_copysignf(0.5f, o[h]);
+            const float v = q4[h] + __builtin_copysignf(0.5f, q4[h]);
             uint8_t *px = base + (jp * 2 + h) * PIX_STRIDE;
-            *px = (uint8_t)med3i((int)v + (int)*px, 0, 255);
+            *px = (uint8_t)med3i(strip_is_zero ? (int)v : (int)v + (int)*px, 0, 255);
         }
     }
 }

@@ -129,7 +129,7 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
                     }
                 }
                 if (n_active > 0)
-                    for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special);
+                    for (int l = 0; l < 64; l++) recon_phase_idct_cols(*s, ri[l], l, rows_from_mask(rm), rows_any, cols_any, any_special, /*strip_is_zero=*/!mc);
             }
             for (int l = 0; l < 64; l++) recon_phase_store(a, *s, l, p, km);
         }

@@ -303,10 +303,17 @@ H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n, 
     (void)n;
     return;
 #endif
+    if (n <= 1) {                                    // uniform
 #pragma unroll
-    for (int ip = 0; ip < 4; ip++) out[ip] = first;
+        for (int ip = 0; ip < 4; ip++) out[ip] = first;
+        return;
+    }
+    // (the second term is added to the one register pair that holds the first: written as `out = first` followed by the
+    // loop from f = 1, the compiler copies the first term into all eight result registers ahead of the branch)
 #pragma unroll
-    for (int f = 1; f < 8; f++) {
+    for (int ip = 0; ip < 4; ip++) out[ip] = first + splat2(in[1]) * basis_pair(B, 1, ip);
+#pragma unroll
+    for (int f = 2; f < 8; f++) {
         if (f >= n) break;
 #pragma unroll
         for (int ip = 0; ip < 4; ip++) {

@@ -226,16 +226,22 @@ H263_CONST_TABLE float kBasis[8][8] = {H263MI_BASIS_ROWS};    // idct.rs:39-48
 // rounds; a power of two commutes with every IEEE rounding on the way (no product or partial sum comes anywhere near
 // the subnormal range: the smallest non-zero one is ~0.19 * 0.19 / 4), so sum(in[f] * (B[f][i] / 4)) IS sum(in[f] *
 // B[f][i]) / 4, bit for bit, and the multiplication by 0.25 costs nothing.
-struct BasisQuarter {
+template <int DIVISOR>
+struct BasisScaled {
     float v[8][8];
-    constexpr BasisQuarter() : v{}
+    constexpr BasisScaled() : v{}
     {
         constexpr float b[8][8] = {H263MI_BASIS_ROWS};
         for (int f = 0; f < 8; f++)
-            for (int i = 0; i < 8; i++) v[f][i] = b[f][i] * 0.25f;
+            for (int i = 0; i < 8; i++) v[f][i] = b[f][i] * (1.0f / DIVISOR);
     }
 };
+typedef BasisScaled<4> BasisQuarter;
 H263_CONST_TABLE BasisQuarter kBasisQuarter = BasisQuarter();
+// ... and times 1/16, for the row pass: the dequantiser hands the coefficients on times 16 (dequant_pair_i16), the same
+// argument makes sum((16 c[f]) * (B[f][i] / 16)) = sum(c[f] * B[f][i]) bit for bit.
+typedef BasisScaled<16> BasisSixteenth;
+H263_CONST_TABLE BasisSixteenth kBasisSixteenth = BasisSixteenth();
 
 H263_DEV f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
 // four consecutive floats (16-byte aligned) in one store
@@ -276,6 +282,16 @@ H263_DEV BasisPtr basis_table_quarter()
     return kBasisQuarter.v;
 #endif
 }
+H263_DEV BasisPtr basis_table_sixteenth()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    BasisPtr b = (BasisPtr)kBasisSixteenth.v;
+    asm volatile("" : "+s"(b));
+    return b;
+#else
+    return kBasisSixteenth.v;
+#endif
+}
 H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], B[f][2 * ip + 1]}; return r; }
 
 // idct_1d (idct.rs:52-65): out[i] = sum over f, in order, of in[f] * B[f][i].  The leading
@@ -283,12 +299,13 @@ H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], 
 // Only the terms f < n are accumulated: the caller guarantees in[f] == 0 for f >= n, and adding a
 // zero product changes nothing but (again) the sign of a zero.  n is uniform over the wave, so the
 // early exits are scalar branches.
-H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n, bool first_term_raw = false)
+H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n, bool first_term_raw = false, float raw_scale = 1.0f)
 {
     // first_term_raw: the row pass of a Vert / Dc block hands in[0] on unscaled (see recon_phase_idct_rows); row 0
     // of the basis is one constant
     // (idct.rs:40: BASIS_TABLE[0][i] = 0.70710677 for every i)
-    const f32x2 first = splat2(in[0]) * splat2(first_term_raw ? 1.0f : B[0][0]);
+    // (raw_scale: what `in` is scaled by relative to the table -- a power of two; 1 / raw_scale takes it out again)
+    const f32x2 first = splat2(in[0]) * splat2(first_term_raw ? raw_scale : B[0][0]);
 #if defined(H263MI_MUTATE_PAIRWISE)
     // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the eight rounded products summed as a balanced
     // tree instead of in the order of the frequency index.  The parity suite must notice.
@@ -340,26 +357,30 @@ H263_HD int rows_from_mask(uint32_t row_mask)       // bit r: some block has a n
 
 // rle.rs:130-133 for two LEVELs at once, as they arrive (a pair of int16 in one dword):
 // sign(L) * (q*(2|L|+1) - (q even)) = L*2q + sign(L)*(q - parity), clamped to [-2048, 2047]; 0 stays 0.
-// Packed 16-bit integer arithmetic; the multiply-add saturates to the i16 range (the reference's i16 product would
-// overflow for 11-bit LEVELs at large quantisers; a saturated value lands on the same side of the final clamp).
-// `two_q2`, `qmp2`: 2q and q - parity in both halves of a dword.
+// Returns SIXTEEN TIMES that value in each half: computed as L * 32q + sign(L) * 16 (q - parity) with a saturating
+// multiply-add, the clamp to 12 bits IS the saturation to 16 bits -- a value beyond it lands on 32767 or -32768, and
+// with the four low bits cleared those are 16 * 2047 and 16 * -2048 (every other result is a multiple of 16 already).
+// One multiply-add and one AND instead of a multiply-add and two clamps; the row pass takes the factor out again
+// through its table (kBasisSixteenth).  The reference's i16 product overflows for 11-bit LEVELs at large quantisers; a
+// saturated value lands on the same side of the clamp.
+// `two_q2`, `qmp2`: 2q and q - parity in both halves of a dword (2q <= 62, q - parity <= 31: times 16 they fit 10 bits).
+constexpr float DEQUANT_SCALE = 16.0f;
 H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qmp2)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     // all in inline asm: written with vector min/max the compiler turns the sign into four compares and selects
     uint32_t sg, t, v;
     asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]" : "=&v"(sg) : "v"(levels));   // -1, 0 or +1
-    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2));
-    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
-    asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_i16 %0, %0, %3" : "=&v"(t) : "v"(v), "v"(0xf800f800u), "v"(0x07ff07ffu));
-    return t;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2 << 4));
+    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2 << 4), "v"(t));
+    return v & 0xfff0fff0u;
 #else
     uint32_t out = 0;
     for (int h = 0; h < 2; h++) {
         const int level = (int)(int16_t)(levels >> (16 * h));
         const int two_q = (int)(two_q2 & 0xffffu), qmp = (int)(int16_t)(qmp2 & 0xffffu);
         const int sg = level > 0 ? 1 : (level < 0 ? -1 : 0);
-        const int v = clampi(level * two_q + sg * qmp, -2048, 2047);
+        const int v = clampi(16 * (level * two_q + sg * qmp), -32768, 32767) & ~15;
         out |= ((uint32_t)v & 0xffffu) << (16 * h);
     }
     return out;
@@ -808,11 +829,11 @@ H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
             C[2 * j + 1] = (float)((int)v >> 16);
         }
     }
-    if (use_dc) C[0] = (float)(int)desc_level(ri.d1);
+    if (use_dc) C[0] = (float)(int)(desc_level(ri.d1) * (uint32_t)DEQUANT_SCALE);     // (at most 2032 * 16)
 
-    // idct_1d over the coefficient row (idct.rs:52-65)
+    // idct_1d over the coefficient row (idct.rs:52-65); C holds 16 x the coefficients, the table 1/16 of the basis
     f32x2 T[4];
-    idct_1d_pairs(basis_table(), C, T, n_cols, first_column_only);
+    idct_1d_pairs(basis_table_sixteenth(), C, T, n_cols, first_column_only, 1.0f / DEQUANT_SCALE);
     float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW], T[0], T[1]);
     float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW + 4], T[2], T[3]);
 }

@@ -764,8 +764,12 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     uint4 raw = f.coef0;                                        // round 0 was loaded ahead of time by recon_phase_fetch
     ri.d1 = f.d1;
     if (round > 0) {                                            // uniform
-        d0 = s.desc[k % WAVE_TASKS][0];
-        ri.d1 = s.desc[k % WAVE_TASKS][1];
+        // (k < WAVE_TASKS: a round starts below the number of active tasks, which are at most WAVE_TASKS, a multiple
+        // of ROUND_BLOCKS; the minimum is one instruction where `k % WAVE_TASKS` was eight)
+        static_assert(WAVE_TASKS % ROUND_BLOCKS == 0, "the last round must end inside the descriptor array");
+        const int kk = k < WAVE_TASKS - 1 ? k : WAVE_TASKS - 1;
+        d0 = s.desc[kk][0];
+        ri.d1 = s.desc[kk][1];
     }
     const bool has = ri.active && d0 != NO_COEFFS;
     if (a.events) {                                             // uniform
@@ -776,6 +780,12 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
         // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r)
         raw = load16_stream(coeff_row_address(a, p, d0, ri.active, r));
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(!has) == 0) {                                  // uniform: every lane of the round has a block (dense pictures)
+        ri.w[0] = raw.x; ri.w[1] = raw.y; ri.w[2] = raw.z; ri.w[3] = raw.w;
+        return;
+    }
+#endif
     ri.w[0] = has ? raw.x : 0u; ri.w[1] = has ? raw.y : 0u; ri.w[2] = has ? raw.z : 0u; ri.w[3] = has ? raw.w : 0u;
 }
 

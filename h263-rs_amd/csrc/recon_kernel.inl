@@ -900,7 +900,9 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
         const f32x2 q4 = O[jp];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const float v = q4[h] + __builtin_copysignf(0.5f, q4[h]);
+            // (strip_is_zero: the pixel is clamp(r, 0, 255).  A negative quarter gives r <= 0 with either sign of the
+            // half -- trunc(q - 0.5) <= 0 and trunc(q + 0.5) <= 0 for q < 0 -- so the half is added as it is)
+            const float v = q4[h] + (strip_is_zero ? 0.5f : __builtin_copysignf(0.5f, q4[h]));
             uint8_t *px = base + (jp * 2 + h) * PIX_STRIDE;
             *px = (uint8_t)med3i(strip_is_zero ? (int)v : (int)v + (int)*px, 0, 255);
         }

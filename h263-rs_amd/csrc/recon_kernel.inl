@@ -754,6 +754,9 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
     }
 }
 
+// (Requesting the NEXT round's coefficient row a round early -- so that it arrives under this round's arithmetic
+// instead of being waited for at the top of its own round -- was measured and dropped: dense I pictures +0.9...+1.4 %,
+// 65 instead of 62 vector registers; profiles/README.md r03_v.)
 H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const WaveFetch &f, int lane, const WavePos &p,
                                     int round, RowIn &ri, const WaveMasks &km, int events_stage = -1)
 {
@@ -782,6 +785,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__ballot(!has) == 0) {                                  // uniform: every lane of the round has a block (dense pictures)
+        asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));    // (keeps this a branch: as selects it saves nothing)
         ri.w[0] = raw.x; ri.w[1] = raw.y; ri.w[2] = raw.z; ri.w[3] = raw.w;
         return;
     }

@@ -503,3 +503,42 @@ def test_batch_decode_events_matches_the_oracle(w, h, n, pipeline):
 def simlib_pad(mbs, w, h):
     import simlib
     return simlib.pad_records(mbs, w, h)
+
+
+# ---------------------------------------------------------------------------------------------
+# The dequantiser at every LEVEL and every quantiser.  The kernels compute 16 x the dequantised value with a saturating
+# 16-bit multiply-add whose saturation IS the reference's clamp to [-2048, 2047] (rle.rs:130-133), and take the factor
+# out again through the row pass's basis table (recon_kernel.inl: dequant_pair_i16, kBasisSixteenth): every one of the
+# 4 094 non-zero 12-bit LEVELs at every quantiser 1..31 -- all overflow and saturation cases included -- as the AC
+# coefficients of Full-class intra blocks, and as inter blocks over a flat prediction, against the oracle.
+# ---------------------------------------------------------------------------------------------
+def test_every_level_at_every_quantiser_dequantises_like_the_oracle():
+    w, h = 176, 144                                            # 99 macroblocks = 594 blocks of 63 AC coefficients
+    levels = np.array([v for v in range(-2047, 2048) if v != 0], np.int16)
+    n_blocks = 99 * 6
+    rng = np.random.default_rng(7)
+    for q in range(1, 32):
+        vals = np.concatenate([levels, rng.choice(levels, n_blocks * 63 - len(levels))])
+        rng.shuffle(vals)
+        co = np.zeros((n_blocks, 64), np.int16)
+        co[:, 1:] = vals.reshape(n_blocks, 63)
+        for ptype in (h263mi.PICTURE_I, h263mi.PICTURE_P):
+            mbs = np.zeros(99, orc.MB_RECORD_DTYPE)
+            mbs["quant"] = q
+            mbs["cbp"] = 0x3f
+            mbs["coeff_index"] = np.arange(99) * 6
+            c = co.copy()
+            if ptype == h263mi.PICTURE_I:
+                mbs["mb_type"] = 3
+                mbs["intradc"] = 100
+                ref, st = None, h263mi.H263State()
+            else:
+                mbs["mb_type"] = 0
+                c[:, 0] = vals[:n_blocks]                      # an inter block's first coefficient is a LEVEL like any other
+                st = _flat_state(w, h, 120)
+                ref = tuple(np.full(n, 120, np.uint8) for n in (w * h, w * h // 4, w * h // 4))
+            st.submit_picture(w, h, mbs, c, ptype)
+            rc, want = orc.decode_picture(w, h, mbs, c, ref)
+            assert rc == 0
+            assert_planes_equal(st.get_last_picture().as_yuv(), want, "q %d type %d" % (q, ptype))
+            st.close()

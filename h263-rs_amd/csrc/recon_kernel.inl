@@ -373,6 +373,11 @@ H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qm
     asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]" : "=&v"(sg) : "v"(levels));   // -1, 0 or +1
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2 << 4));
     asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2 << 4), "v"(t));
+#if defined(H263MI_MUTATE_DEQUANT_SATURATION)
+    // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the saturated values keep their low bits, so a LEVEL
+    // beyond the clamp comes out as 2047.9375 instead of 2047.  The every-LEVEL-at-every-quantiser test must notice.
+    return v;
+#endif
     return v & 0xfff0fff0u;
 #else
     uint32_t out = 0;

@@ -81,3 +81,20 @@ def test_mutant_build_is_caught(mutant, tmp_path):
     # the same run through the product build (same process-isolated path) is clean
     clean = run_with(os.path.join(PKG, "libh263mi.so"), tmp_path, "product")
     assert (clean == want).all()
+
+
+def test_dequantiser_mutant_is_caught_by_the_every_level_test():
+    """libh263mi_dequant.so: the dequantiser computes 16 x the value with a saturating multiply-add and clears the four
+    low bits, which is what turns a saturated 32767 into 16 * 2047 (recon_kernel.inl: dequant_pair_i16); the mutant
+    leaves them set.  tests/test_gpu_round3.py::test_every_level_at_every_quantiser_dequantises_like_the_oracle must
+    fail on it and pass on the product (both in fresh processes: the library is chosen at import)."""
+    lib = os.path.join(PKG, "mutants", "libh263mi_dequant.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", PKG, "-s", "mutants"])
+    cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_round3.py"), "-x", "-q", "-k", "every_level",
+           "-p", "no:cacheprovider"]
+    bad = subprocess.run(cmd, env=dict(os.environ, H263MI_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "1 failed" in bad.stdout, bad.stdout[-800:]
+    good = subprocess.run(cmd, env=dict(os.environ, H263MI_LIB=os.path.join(PKG, "libh263mi.so")), capture_output=True,
+                          text=True, timeout=600)
+    assert good.returncode == 0 and "1 passed" in good.stdout, good.stdout[-800:]

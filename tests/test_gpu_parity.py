@@ -436,7 +436,7 @@ def test_batch_submit_host_matches_the_oracle_per_stream():
 
 @pytest.mark.parametrize("w,h", [(176, 144), (100, 60), (16, 16), (320, 240)])
 def test_submit_picture_events_equals_dense_submit(w, h):
-    """sparse coefficient transport (k_expand) against the oracle, incl. blocks without any event, an intra block
+    """sparse coefficient transport (events read by the reconstruction waves) against the oracle, incl. blocks without any event, an intra block
     whose element 0 is set in the dense form (ignored there, absent here), and duplicate positions"""
     st = h263mi.H263State()
     mbs, co = recgen.intra_picture(w, h, seed=w + 1, max_level=127)

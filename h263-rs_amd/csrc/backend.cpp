@@ -240,6 +240,8 @@ struct h263mi_batch {
             const size_t set_bytes = (size_t)n * L.frame_bytes;
             HIP_TRY(hipMalloc((void **)&frames[0], 2 * set_bytes));
             frames[1] = frames[0] + set_bytes;
+            if (getenv("H263MI_TRACE_ALLOC"))
+                fprintf(stderr, "h263mi frame store: %p .. +%zu\n", (void *)frames[0], 2 * set_bytes);
             HIP_TRY(hipMemsetAsync(frames[0], 0, 2 * set_bytes, stream));
         }
         if (!d_status) {

@@ -34,6 +34,14 @@ static void sim_post_tile(const PostArgs &a, PostStrip &s, PostFetch (*pf)[64], 
 
 extern "C" {
 
+// the dequantiser of the reconstruction waves on a whole table of LEVELs at one quantiser (pairs of int16 in, pairs of
+// int16 out: SIXTEEN TIMES the clamped value, recon_kernel.inl: dequant_pair_i16), for tests/test_sim_kernels.py
+void sim_dequant_pairs(const uint32_t *levels, uint32_t n_pairs, uint32_t quant, uint32_t *out)
+{
+    const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = ((quant - 1u) | 1u) * 0x00010001u;
+    for (uint32_t i = 0; i < n_pairs; i++) out[i] = dequant_pair_i16(levels[i], two_q2, qmp2);
+}
+
 void sim_layout(uint32_t w, uint32_t h, FrameLayout *out) { *out = make_layout(w, h); }
 
 // block_first_event / events: sparse coefficient transport consumed by the reconstruction wave itself (nullptr: dense)

@@ -275,3 +275,23 @@ def test_recon_static_waves_take_the_copy_path(w, h):
     assert st == 0
     for g, e in zip(got, ref):
         assert (g == e).all()
+
+
+def test_dequantiser_every_level_every_quantiser_is_sixteen_times_the_clamped_value():
+    """recon_kernel.inl: dequant_pair_i16 hands on 16 x sign(L) * clamp(q * (2|L| + 1) - (q even), ..) (rle.rs:130-133
+    with the clamp to [-2048, 2047]) for every 16-bit LEVEL a record can carry, at every quantiser -- the portable form
+    of the device's saturating multiply-add (the device form itself: tests/test_gpu_round3.py and the dequant mutant)."""
+    import ctypes as C
+    L = simlib.lib()
+    L.sim_dequant_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lv = np.arange(-2047, 2048, dtype=np.int16)
+    lv = np.concatenate([lv, np.zeros(1, np.int16)])            # an even count: pairs
+    packed = np.ascontiguousarray(lv).view(np.uint32)
+    out = np.empty_like(packed)
+    for q in range(1, 32):
+        L.sim_dequant_pairs(packed.ctypes.data, len(packed), q, out.ctypes.data)
+        got = out.view(np.int16).astype(np.int64)
+        l64 = lv.astype(np.int64)
+        want = np.sign(l64) * (q * (2 * np.abs(l64) + 1) - (1 if q % 2 == 0 else 0))
+        want = np.clip(want, -2048, 2047)
+        assert (got == 16 * want).all(), q

@@ -110,7 +110,11 @@ def run(budget=60.0, seed=1, verbose=True):
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     n_pic = n_px = 0
+    t_note = time.time() + 60.0
     while time.time() < t_end:
+        if verbose and time.time() >= t_note:                    # (a long run must not look hung to the GPU box's watchdog)
+            print("  ... %d pictures so far" % n_pic, flush=True)
+            t_note = time.time() + 60.0
         # (the last entries: sizes with several interior tiles of k_post per row and column, widths that are / are not
         # multiples of 4 and 8 -- the wrap of the left picture columns into the last tile and the floor / truncation
         # regions of the deblocking filter depend on them)

@@ -304,9 +304,10 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     constexpr uint32_t kUnitsPerTile = TILE_WAVES / RECON_WAVES;
     const uint32_t upp = a.tiles_x * a.tiles_y * kUnitsPerTile;           // work items of one picture
     // a picture's list is dealt to a.bands XCDs in contiguous chunks, 8 / a.bands pictures side by side (see k_frame)
-    const uint32_t bands = a.bands, xcd = blockIdx.x & 7;
-    const uint32_t chunk = (upp + bands - 1) / bands, t = blockIdx.x >> 3, g = (xcd & (bands - 1)) * chunk + t;
-    const uint32_t pic = blockIdx.y * (8 / bands) + xcd / bands;
+    // (bands is a power of two: shifts -- as divisions by a run-time value they were 60 scalar instructions per wave)
+    const uint32_t bands = a.bands, bsh = (uint32_t)__builtin_ctz(bands), xcd = blockIdx.x & 7;
+    const uint32_t chunk = (upp + bands - 1) >> bsh, t = blockIdx.x >> 3, g = (xcd & (bands - 1)) * chunk + t;
+    const uint32_t pic = blockIdx.y * (8u >> bsh) + (xcd >> bsh);
     if (t >= chunk || g >= upp || pic >= a.n_pictures) return;
     const uint32_t tile = g / kUnitsPerTile;                               // power of two
     const int tw = (int)(g % kUnitsPerTile) * RECON_WAVES + wave;          // macroblock row of the tile
@@ -483,10 +484,11 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
     // A picture's work list is dealt to `bands` XCDs in contiguous chunks, 8 / bands pictures side by side (fg.bands:
     // 8, 4 or 2; blockIdx.y counts sets of 8 / bands pictures).  Fewer, taller bands: fewer band borders, whose
     // reference rows two L2s fetch.
-    const uint32_t bands = fg.bands, xcd = blockIdx.x & 7;
-    const uint32_t chunk = (upp + bands - 1) / bands, band = xcd & (bands - 1), side = xcd / bands;
+    // (bands is a power of two: shifts -- as divisions by a run-time value they were 60 scalar instructions per wave)
+    const uint32_t bands = fg.bands, bsh = (uint32_t)__builtin_ctz(bands), xcd = blockIdx.x & 7;
+    const uint32_t chunk = (upp + bands - 1) >> bsh, band = xcd & (bands - 1), side = xcd >> bsh;
     const uint32_t t = blockIdx.x >> 3, g = band * chunk + t;
-    const uint32_t pic_y = blockIdx.y * (8 / bands) + side;
+    const uint32_t pic_y = blockIdx.y * (8u >> bsh) + side;
     if (t >= chunk || g >= upp || pic_y >= ra.n_pictures) return;
     const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group);
     const uint32_t r = g - group * per_group;      // (post tiles in front of the reconstruction waves: no difference)
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
             } else {
                 const uint32_t g3 = g2 - band_end + band * chunk;          // counted from the start of the band
                 const uint32_t group3 = div_tiles_x(g3, per_group, fg.inv_per_group), r3 = g3 - group3 * per_group;
-                const int pic3 = ((int)blockIdx.y + 1) * (int)(8 / bands) + (int)side;
+                const int pic3 = ((int)blockIdx.y + 1) * (int)(8u >> bsh) + (int)side;
                 q.pic = r3 < fg.recon_per_group && pic3 < (int)ra.n_pictures
                             ? (fg.flip ? (int)ra.n_pictures - 1 - pic3 : pic3) : -1;
                 q.mbx0 = (int)(r3 >> 1) * TILE_MBX;

@@ -66,6 +66,12 @@ constexpr int LUMA_TASKS = 32;
 constexpr int ROUND_BLOCKS = 8;                // blocks per IDCT round (8 lanes each)
 constexpr int TBUF_ROW = 8;                    // floats per row of a block slot: T[r][0..7], written as two 16-byte stores
 constexpr int TBUF_STRIDE = 8 * TBUF_ROW + 8;  // 72 floats per slot: 8 pad floats make the column reads bank-conflict free
+// Row r of a slot starts at float 8 r + (r & 4): rows 4..7 sit four floats further.  A 16-byte store is served eight
+// lanes at a time; with plain 8 r the eight rows of a slot start at banks 0, 8, 16, 24, 0, 8, 16, 24 -- a two-way
+// conflict on every row-pass store (most of the launch's LDS bank conflicts); shifted, they cover all 32 banks.  The
+// slot still ends at float 68 < TBUF_STRIDE, and the column reads (one float per lane, eight lanes per slot) stay
+// conflict-free: a constant added per row.
+H263_HD int tbuf_row_offset(int r) { return r * TBUF_ROW + (r & 4); }
 constexpr int PIX_STRIDE = 128;                // bytes per row of the reconstruction strip
 constexpr int PIX_CHROMA = 16 * PIX_STRIDE;    // rows 0..15: luma; rows 16..23: Cb in columns 0..63, Cr in 64..127
 constexpr int MB_LANE0 = WAVE_TASKS;           // lanes 48..55 of the mark phase are the 8 macroblocks
@@ -853,8 +859,8 @@ H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
     // idct_1d over the coefficient row (idct.rs:52-65); C holds 16 x the coefficients, the table 1/16 of the basis
     f32x2 T[4];
     idct_1d_pairs(basis_table_sixteenth(), C, T, n_cols, first_column_only, 1.0f / DEQUANT_SCALE);
-    float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW], T[0], T[1]);
-    float4_store(&s.tbuf[slot * TBUF_STRIDE + r * TBUF_ROW + 4], T[2], T[3]);
+    float4_store(&s.tbuf[slot * TBUF_STRIDE + tbuf_row_offset(r)], T[0], T[1]);
+    float4_store(&s.tbuf[slot * TBUF_STRIDE + tbuf_row_offset(r) + 4], T[2], T[3]);
 }
 
 // ---- phase 4b: column pass, rounding, residual into the strip -----------------------------
@@ -880,7 +886,7 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
     const float *src = &s.tbuf[slot * TBUF_STRIDE + i];
     float col[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) col[r] = r < n_rows ? src[r * TBUF_ROW] : 0.0f;       // uniform: rows >= n_rows are zero
+    for (int r = 0; r < 8; r++) col[r] = r < n_rows ? src[tbuf_row_offset(r)] : 0.0f;   // uniform: rows >= n_rows are zero
 
     // O = a QUARTER of the second pass's result (basis table times 0.25, see kBasisQuarter): what idct.rs:189 rounds
     f32x2 O[4];

@@ -38,10 +38,25 @@ for path in args.libs:
     h263mi.LIB_PATH = os.path.abspath(path)
     handles.append(h263mi.lib())
 h263mi._lib = handles[0]
-batches = []
-for L in handles:
-    h263mi._lib = L
-    batches.append(h263mi.Batch(N, bench.W, bench.H, 0, stream, pipeline_post=True))
+# Every measurement creates its batch and closes it again: the libraries then take turns on ONE frame store's worth of
+# device memory (the allocator hands the block just freed to the next batch).  With a batch per library kept for the whole
+# run, the batch created last ran the P workload 6-9 % slower than its siblings on some boxes, whichever library it
+# belonged to (profiles/README.md r03_v, r03_y): a position in the argument list is not a property of a build.
+batches = [None] * len(handles)
+
+
+class fresh_batch:
+    def __init__(self, L):
+        self.L = L
+
+    def __enter__(self):
+        h263mi._lib = self.L
+        self.b = h263mi.Batch(N, bench.W, bench.H, 0, stream, pipeline_post=True)
+        return self.b
+
+    def __exit__(self, *exc):
+        h263mi._lib = self.L
+        self.b.close()
 
 
 def time_gops(b, w, n_frames, rgba, strength=None):
@@ -68,10 +83,11 @@ for placement in range(args.placements):
     res = [[] for _ in handles]
     resd = [[] for _ in handles]
     for rnd in range(args.rounds + 1):
-        for k, (L, b) in enumerate(zip(handles, batches)):
-            h263mi._lib = L
-            t = time_gops(b, wl, GOP * args.gops, rgba)
-            td = time_gops(b, dense, 60, rgba, 0)
+        for k, L in enumerate(handles):
+            with fresh_batch(L) as b:
+                time_gops(b, wl, GOP, rgba)                      # (the new frame store's first touch)
+                t = time_gops(b, wl, GOP * args.gops, rgba)
+                td = time_gops(b, dense, 60, rgba, 0)
             if rnd:                                  # round 0 warms up
                 res[k].append(t)
                 resd[k].append(td)
@@ -90,6 +106,4 @@ for placement in range(args.placements):
                 if fr.get(key) is not None:
                     fr[key].free()
     spacers.append(h263mi.DeviceBuffer(((placement * 41) % 89 + 5) << 20, 0))
-for L, b in zip(handles, batches):
-    h263mi._lib = L
-    b.close()
+

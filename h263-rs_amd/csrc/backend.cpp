@@ -222,6 +222,7 @@ struct h263mi_batch {
     // destroyed): [0] parser threads, [1] waiting for the staging slot, [2] packing into pinned staging, [3] enqueueing
     // copies and launches
     double host_ms[4] = {0, 0, 0, 0};
+    size_t frame_skew = 0;
     unsigned host_calls = 0;
     bool trace_host = getenv("H263MI_TRACE_E2E") != nullptr;
     // timing
@@ -238,7 +239,13 @@ struct h263mi_batch {
         // both frame sets in one allocation
         {
             const size_t set_bytes = (size_t)n * L.frame_bytes;
-            HIP_TRY(hipMalloc((void **)&frames[0], 2 * set_bytes));
+            // H263MI_EXP_FRAME_SKEW (experiment, a multiple of 16): the whole frame store starts that many bytes past a
+            // 64-byte line, so that no row of any plane is line-aligned (profiles/README.md r03_zz: aligned RGBA runs
+            // are 10 % slower than runs that start 16 bytes into a line -- the same for the planes?)
+            const char *skew_env = getenv("H263MI_EXP_FRAME_SKEW");
+            frame_skew = skew_env ? ((size_t)atoi(skew_env) & 0xff0u) : 0;
+            HIP_TRY(hipMalloc((void **)&frames[0], 2 * set_bytes + 4096));
+            frames[0] += frame_skew;
             frames[1] = frames[0] + set_bytes;
             if (getenv("H263MI_TRACE_ALLOC"))
                 fprintf(stderr, "h263mi frame store: %p .. +%zu\n", (void *)frames[0], 2 * set_bytes);
@@ -315,7 +322,7 @@ struct h263mi_batch {
 
     void release_frames()
     {
-        if (frames[0]) (void)hipFree(frames[0]);         // (one allocation holds both sets)
+        if (frames[0]) (void)hipFree(frames[0] - frame_skew);         // (one allocation holds both sets)
         frames[0] = frames[1] = nullptr;
     }
 

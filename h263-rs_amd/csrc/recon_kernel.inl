@@ -11,8 +11,9 @@
 // operations of one wave executing in order.  One wave is one workgroup (its LDS and registers are released when it
 // ends); the XCD-aware work order of kernels.hip keeps neighbouring waves on one L2.
 //
-// Round 3 redesign (profiles/README.md, r03): the kernel is bound by vector-instruction issue, so the wave was reshaped
-// to execute fewer instructions per reconstructed byte:
+// Round 3 redesign (profiles/README.md, r03): the wave was reshaped to execute fewer instructions -- vector, scalar and
+// vector-memory alike -- per reconstructed byte (what limits the launch is the CU's memory pipeline with the vector ALUs
+// close behind it: DESIGN.md section 3, "What bounds the kernels"):
 //   * 8 whole macroblocks per wave instead of half of them: records, prologue and the mark phase are paid once for
 //     twice the pixels, and the IDCT rounds (8 blocks each) are filled from 48 tasks instead of 24;
 //   * the reconstruction is assembled in a BYTE strip in LDS: the prediction is written there first, the lanes of the

@@ -322,7 +322,8 @@ int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263
  * (n_mbs[s] <= mbs_per_picture; missing ones are padded as Inter / mv 0, state.rs:421-427) and coded blocks
  * (coeff_index counts from the stream's own first block).  The arrays are packed into pinned staging -- two slots,
  * used alternately, so packing picture i+1 overlaps the copy and the kernel of picture i -- copied with one
- * asynchronous H2D per array and decoded by one k_recon launch.  The host arrays may be reused on return.
+ * asynchronous H2D per array and decoded by one launch (k_recon; k_frame on a H263MI_CFG_PIPELINE_POST batch with a
+ * deferred post-processing pending).  The host arrays may be reused on return.
  * Records are validated like h263mi_submit_picture validates them (types, quantiser, coded block indices against
  * n_coeff_blocks[s]; H263MI_ERR_INVALID_ARGUMENT before anything is queued); an inter macroblock without a
  * reference picture surfaces at h263mi_batch_sync like for h263mi_batch_submit.
@@ -340,7 +341,8 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  * N x H263State::decode_next_picture(reader) (state.rs:138-141) in one call: data[s] / len[s] hold one coded picture
  * of stream s (what Ruffle hands one reader per FLV video tag).  The serial parse of each stream (state.rs:143-427)
  * runs on `n_threads` host threads (0 = one per hardware thread), one stream per task; the records of all streams
- * then cross to the device as events (h263mi_batch_submit_host_events) and one k_recon launch decodes them.
+ * then cross to the device as events (h263mi_batch_submit_host_events) and ONE launch decodes them: k_recon, or -- on a
+ * H263MI_CFG_PIPELINE_POST batch through the _ex form -- k_frame, which also post-processes the previous picture.
  * consumed[s] (may be NULL) receives the bytes used.  decoder_options as for h263mi_state_new.  If any stream fails
  * to parse, the error of the first such stream is returned and NOTHING changes for any stream.  Every picture must
  * have the batch's width and height.  The host parser is the bit-at-a-time reader of the reference (reader.rs:94-134,

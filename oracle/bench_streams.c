@@ -30,11 +30,18 @@ typedef struct {
     int id, n_gops, n_frames;
     uint16_t w, h;
     uint8_t strength;
+    int stages;                         /* ORC_STAGE_* bits: which stages run inside the clock */
+    int simd;                           /* 1: deblock / BT.601 in their explicit 128-bit form (simd_stages.c) */
     const orc_bench_picture *pics;      /* n_frames pictures of this thread's stream */
     pthread_barrier_t *start, *stop;
     uint64_t checksum;
     int rc;
 } worker_t;
+
+enum { ORC_STAGE_RECON = 1, ORC_STAGE_DEBLOCK = 2, ORC_STAGE_RGBA = 4 };
+int orc_deblock_simd(const uint8_t *data, size_t len, size_t width, uint8_t strength, uint8_t *out);
+int orc_yuv420_to_rgba_simd(const uint8_t *y, size_t y_len, const uint8_t *cb, const uint8_t *cr, size_t c_len, size_t y_width,
+                            uint8_t *rgba);
 
 static uint64_t fold(uint64_t acc, const uint8_t *p, size_t n)
 {
@@ -67,6 +74,27 @@ static void *worker(void *arg)
         memset(rgba, 0, ny * 4);
     }
     wk->rc = ok ? ORC_OK : ORC_ERR_INVALID_ARGUMENT;
+    int (*const deblock)(const uint8_t *, size_t, size_t, uint8_t, uint8_t *) = wk->simd ? orc_deblock_simd : orc_deblock;
+    int (*const to_rgba)(const uint8_t *, size_t, const uint8_t *, const uint8_t *, size_t, size_t, uint8_t *) =
+        wk->simd ? orc_yuv420_to_rgba_simd : orc_yuv420_to_rgba;
+    const int st = wk->stages;
+    if (ok && !(st & ORC_STAGE_RECON)) {
+        /* a stage timed on its own works on one fixed picture: the stream's first picture (and its second on top of it,
+         * when there is one), decoded and -- for the conversion alone -- filtered before the clock starts */
+        const orc_bench_picture *p = &wk->pics[0];
+        int rc = orc_decode_picture(wk->w, wk->h, p->mbs, p->n_mbs, p->coeffs, p->n_blocks, NULL, NULL, NULL, buf[1][0], buf[1][1], buf[1][2]);
+        if (rc == ORC_OK && wk->n_frames > 1) {
+            p = &wk->pics[1];
+            rc = orc_decode_picture(wk->w, wk->h, p->mbs, p->n_mbs, p->coeffs, p->n_blocks, buf[1][0], buf[1][1], buf[1][2],
+                                    buf[0][0], buf[0][1], buf[0][2]);
+        } else if (rc == ORC_OK) {
+            for (int k = 0; k < 3; k++) memcpy(buf[0][k], buf[1][k], k ? nc : ny);
+        }
+        if (rc == ORC_OK) rc = orc_deblock(buf[0][0], ny, w, wk->strength, filt[0]);
+        if (rc == ORC_OK) rc = orc_deblock(buf[0][1], nc, cw, wk->strength, filt[1]);
+        if (rc == ORC_OK) rc = orc_deblock(buf[0][2], nc, cw, wk->strength, filt[2]);
+        if (rc != ORC_OK) { wk->rc = rc; ok = 0; }
+    }
     pthread_barrier_wait(wk->start);
     uint64_t acc = 0xcbf29ce484222325ull;
     for (int g = 0; ok && g < wk->n_gops; g++) {
@@ -75,17 +103,24 @@ static void *worker(void *arg)
             const orc_bench_picture *p = &wk->pics[f];
             uint8_t **out = buf[cur], **ref = buf[cur ^ 1];
             const int has_ref = f > 0;                    /* frame 0 of a GOP is an I picture */
-            int rc = orc_decode_picture(wk->w, wk->h, p->mbs, p->n_mbs, p->coeffs, p->n_blocks,
+            int rc = ORC_OK;
+            if (st & ORC_STAGE_RECON)
+                rc = orc_decode_picture(wk->w, wk->h, p->mbs, p->n_mbs, p->coeffs, p->n_blocks,
                                         has_ref ? ref[0] : NULL, has_ref ? ref[1] : NULL, has_ref ? ref[2] : NULL,
                                         out[0], out[1], out[2]);
-            if (rc == ORC_OK) rc = orc_deblock(out[0], ny, w, wk->strength, filt[0]);
-            if (rc == ORC_OK) rc = orc_deblock(out[1], nc, cw, wk->strength, filt[1]);
-            if (rc == ORC_OK) rc = orc_deblock(out[2], nc, cw, wk->strength, filt[2]);
-            if (rc == ORC_OK) rc = orc_yuv420_to_rgba(filt[0], ny, filt[1], filt[2], nc, w, rgba);
+            else
+                out = buf[0];                             /* the fixed picture */
+            if (st & ORC_STAGE_DEBLOCK) {
+                if (rc == ORC_OK) rc = deblock(out[0], ny, w, wk->strength, filt[0]);
+                if (rc == ORC_OK) rc = deblock(out[1], nc, cw, wk->strength, filt[1]);
+                if (rc == ORC_OK) rc = deblock(out[2], nc, cw, wk->strength, filt[2]);
+            }
+            if ((st & ORC_STAGE_RGBA) && rc == ORC_OK) rc = to_rgba(filt[0], ny, filt[1], filt[2], nc, w, rgba);
             if (rc != ORC_OK) { wk->rc = rc; ok = 0; break; }
             acc = fold(acc, out[0], ny);
-            acc = fold(acc, rgba, ny * 4);
-            cur ^= 1;
+            if (st & ORC_STAGE_DEBLOCK) acc = fold(acc, filt[0], ny);
+            if (st & ORC_STAGE_RGBA) acc = fold(acc, rgba, ny * 4);
+            if (st & ORC_STAGE_RECON) cur ^= 1;
         }
     }
     pthread_barrier_wait(wk->stop);
@@ -107,9 +142,23 @@ static double now_s(void)
  * stream t % n_distinct (pics[(t % n_distinct) * n_frames + f], shared read-only).  Returns the wall-clock seconds
  * between the moment all threads are ready (buffers allocated and touched) and the moment the last one finishes,
  * or a negative error code.  checksums[t] (may be NULL) receives a digest of thread t's outputs. */
+double orc_bench_stages(int n_threads, int n_gops, int n_frames, uint16_t w, uint16_t h, const orc_bench_picture *pics,
+                        int n_distinct, uint8_t strength, int stages, int simd, uint64_t *checksums);
 double orc_bench_streams(int n_threads, int n_gops, int n_frames, uint16_t w, uint16_t h,
                          const orc_bench_picture *pics, int n_distinct, uint8_t strength, uint64_t *checksums)
 {
+    return orc_bench_stages(n_threads, n_gops, n_frames, w, h, pics, n_distinct, strength,
+                            ORC_STAGE_RECON | ORC_STAGE_DEBLOCK | ORC_STAGE_RGBA, 0, checksums);
+}
+
+/* The same with a choice of stages ("recon / deblock / yuv->rgba individually and end-to-end"):
+ * `stages` = ORC_STAGE_* bits; a stage that runs without the reconstruction works on one fixed picture of the stream,
+ * n_gops x n_frames times.  simd: deblock and BT.601 in the reference's explicit 128-bit shape (simd_stages.c) instead of
+ * the oracle's one-lane-at-a-time restatement. */
+double orc_bench_stages(int n_threads, int n_gops, int n_frames, uint16_t w, uint16_t h, const orc_bench_picture *pics,
+                        int n_distinct, uint8_t strength, int stages, int simd, uint64_t *checksums)
+{
+    if (!(stages & 7) || (stages & ~7)) return -100.0;
     if (n_threads < 1 || n_gops < 1 || n_frames < 1 || n_distinct < 1 || !pics || !w || !h) return -100.0;
     /* Like the reference (state.rs:179-191), the oracle allocates its per-picture block arrays anew for every picture
      * (about 13 MB at 1080p).  With glibc's defaults each of those is an mmap + page-fault storm + munmap, and with one
@@ -129,6 +178,7 @@ double orc_bench_streams(int n_threads, int n_gops, int n_frames, uint16_t w, ui
     for (int t = 0; t < n_threads; t++) {
         wk[t].id = t; wk[t].n_gops = n_gops; wk[t].n_frames = n_frames;
         wk[t].w = w; wk[t].h = h; wk[t].strength = strength;
+        wk[t].stages = stages; wk[t].simd = simd;
         wk[t].pics = pics + (size_t)(t % n_distinct) * (size_t)n_frames;
         wk[t].start = &start; wk[t].stop = &stop;
         if (pthread_create(&th[t], NULL, worker, &wk[t])) break;

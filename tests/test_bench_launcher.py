@@ -41,3 +41,16 @@ def test_fewer_devices_than_requested_is_an_error_not_a_smaller_job():
 def test_world_size_must_match_gpus():
     r = _run(["--gpus", "1"], {"H263MI_BENCH_STUB": "1", "WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE 2 != --gpus 1" in r.stderr
+
+
+def test_gpus_8_stub_weak_and_strong():
+    """BASELINE configs[4]: 512 streams over 8 GPUs.  The launcher, rendezvous, barrier and aggregation at the node's full
+    rank count (CPU stand-in, gloo): weak scaling (64 streams per rank) and the strong form (--total-streams 512)."""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0"], {"H263MI_BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["pictures"] == 8 * 64 * 31 * 4
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0", "--total-streams", "512"], {"H263MI_BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["pictures"] == 512 * 31 * 4

@@ -1,9 +1,9 @@
 #!/bin/bash
-# build/lib_<name>.so = the library built with extra -D flags (A/B and timing-only experiments; tools/ab.sh runs them)
+# ab_libs/lib_<name>.so = the library built with extra -D flags (A/B and timing-only experiments; tools/ab.sh runs them)
 # usage: bash tools/build_variant.sh <name> [-DMACRO[=v] ...]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
-mkdir -p $R/build
+mkdir -p $R/ab_libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-strict-aliasing -Wall -Wno-unused-function \
-  "$@" -x hip -shared -o $R/build/lib_$NAME.so $R/h263-rs_amd/csrc/kernels.hip $R/h263-rs_amd/csrc/backend.cpp $R/h263-rs_amd/host/bitstream.cpp
+  "$@" -x hip -shared -o $R/ab_libs/lib_$NAME.so $R/h263-rs_amd/csrc/kernels.hip $R/h263-rs_amd/csrc/backend.cpp $R/h263-rs_amd/host/bitstream.cpp

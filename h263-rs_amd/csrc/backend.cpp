@@ -42,10 +42,23 @@ int map_hip_error(hipError_t e)
     }
 }
 
-#define HIP_TRY(expr)                                    \
-    do {                                                 \
-        hipError_t _e = (expr);                          \
-        if (_e != hipSuccess) return map_hip_error(_e);  \
+// Fault injection for tests (h263mi_debug_fail_nth_hip_call): the n-th HIP call made through HIP_TRY from now on is not
+// executed and reports hipErrorOutOfMemory instead.  Every allocation, copy, event operation and launch of the host entry
+// points goes through HIP_TRY, so sweeping n over a call proves "on error the state is unchanged" (state.rs:142, 464-487)
+// at every point at which the call can fail.  -1 = off (the product never sets it).
+std::atomic<int> g_fail_countdown{-1};
+bool fault_now()
+{
+    int v = g_fail_countdown.load(std::memory_order_relaxed);
+    if (v < 0) return false;
+    v = g_fail_countdown.fetch_sub(1, std::memory_order_relaxed);
+    return v == 1;                                 // the countdown went 1 -> 0 with this call
+}
+
+#define HIP_TRY(expr)                                                      \
+    do {                                                                   \
+        hipError_t _e = fault_now() ? hipErrorOutOfMemory : (expr);        \
+        if (_e != hipSuccess) return map_hip_error(_e);                    \
     } while (0)
 
 #define RC_TRY(expr)                  \
@@ -191,6 +204,7 @@ struct h263mi_batch {
     hipEvent_t state_copied[kStateSlots] = {nullptr, nullptr, nullptr, nullptr};
     unsigned state_slot = 0;
     const uint32_t *cur_first_event = nullptr, *cur_events = nullptr;   // sparse transport of the next submit (then cleared)
+    uint32_t cur_n_events = 0;                 // ... and how many event words there are (0 = the caller did not say)
     uint64_t coeff_pool_blocks = 0;            // size of the pool the next submit reads ...
     bool coeff_checked = false;                // ... when the caller told us (host entry points do; device pointers do not)
     // (what sync() falls back to when the device reports an error -- state.rs:142, 464-487: an error leaves the state
@@ -285,15 +299,16 @@ struct h263mi_batch {
         return true;
     }
     // hand the kernels one word per stream: fills the next slot of the ring and queues its copy
-    int push_stream_words(const std::vector<uint32_t> &words, const uint32_t **d_out)
+    // `on`: the stream whose kernel reads the words (the copy is ordered in front of that kernel by being on its stream)
+    int push_stream_words(const std::vector<uint32_t> &words, const uint32_t **d_out, hipStream_t on)
     {
         const unsigned slot = state_slot++ % kStateSlots;
         HIP_TRY(hipEventSynchronize(state_copied[slot]));         // (its previous copy has left the host buffer)
         uint32_t *h = h_state + (size_t)slot * n, *d = d_state + (size_t)slot * n;
         memcpy(h, words.data(), (size_t)n * sizeof(uint32_t));
         RC_TRY(time_close());                                      // a copy is not part of any kernel's time
-        HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(state_copied[slot], stream));
+        HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, on));
+        HIP_TRY(hipEventRecord(state_copied[slot], on));
         *d_out = d;
         return H263MI_OK;
     }
@@ -462,7 +477,9 @@ struct h263mi_batch {
         a.coeffs = d_coeffs;
         a.block_first_event = cur_first_event;
         a.events = cur_events;
+        a.n_events = cur_n_events ? cur_n_events : 0xffffffffu;
         cur_first_event = cur_events = nullptr;
+        cur_n_events = 0;
         a.coeff_base = d_coeff_base;
         a.status = d_status;
         a.coeff_pool_blocks = coeff_pool_blocks;
@@ -496,7 +513,7 @@ struct h263mi_batch {
                 words[i] = w;
             }
             const uint32_t *d_words = nullptr;
-            RC_TRY(push_stream_words(words, &d_words));
+            RC_TRY(push_stream_words(words, &d_words, stream));
             a.stream_state = d_words;
             a.ref = frames[0];                   // (never used with stream_state; never null)
             a.cur = frames[1];
@@ -508,7 +525,10 @@ struct h263mi_batch {
             }
         }
         // the set being overwritten was last read by the post-processing of the picture before the last one
-        if (overlap_post) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out0], 0));
+        if (overlap_post) {
+            HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out0], 0));
+            if (!all_same) HIP_TRY(hipStreamWaitEvent(stream, ev_post_done[out0 ^ 1], 0));     // (streams write either set)
+        }
         if (with_post) {
             RC_TRY(time_begin(2));
             const hipError_t e = launch_frame(a, pa, stream, (frame_launches++ & 1u) != 0);
@@ -566,7 +586,7 @@ struct h263mi_batch {
             for (uint32_t i = 0; i < n; i++)
                 words[i] = STREAM_RECON_SKIP | (sets[i] < 0 ? STREAM_POST_SKIP : (sets[i] == 1 ? STREAM_POST_SET1 : 0u));
             const uint32_t *d_words = nullptr;
-            RC_TRY(push_stream_words(words, &d_words));
+            RC_TRY(push_stream_words(words, &d_words, on));
             a.stream_state = d_words;
             a.frame_set[0] = frames[0];
             a.frame_set[1] = frames[1];
@@ -595,16 +615,27 @@ struct h263mi_batch {
         return launch_post_sets(pending.set, pending.strength, pending.rgba, pending.planes, stream);
     }
 
-    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
+    // only_active: the rendering half of a decode call -- streams that sat the call out (h263mi_batch_set_active, no data,
+    // a picture that failed to parse) keep their part of the output buffers untouched, as the pipelined form (note_pending)
+    // does; h263mi_batch_render_rgba renders every stream's last picture.
+    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, bool only_active = false)
     {
         if (!any_picture()) return H263MI_ERR_NO_PICTURE;
         if (strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
         RC_TRY(flush_pending());
         std::vector<int8_t> sets(n);
-        for (uint32_t i = 0; i < n; i++) sets[i] = ss[i].cur;
+        bool reads[2] = {false, false};
+        for (uint32_t i = 0; i < n; i++) {
+            sets[i] = (only_active && !ss[i].active) ? (int8_t)-1 : ss[i].cur;
+            if (sets[i] >= 0) reads[sets[i]] = true;
+        }
         if (overlap_post) HIP_TRY(hipStreamWaitEvent(post_stream, ev_recon_done, 0));
         RC_TRY(launch_post_sets(sets, strength, d_rgba, d_planes, stream_of(1)));
-        if (overlap_post) HIP_TRY(hipEventRecord(ev_post_done[ss[0].cur >= 0 ? ss[0].cur : 0], post_stream));
+        // a later reconstruction may overwrite a frame set only when every post-processing that reads it is done: streams
+        // that have drifted apart read both sets
+        if (overlap_post)
+            for (int k = 0; k < 2; k++)
+                if (reads[k]) HIP_TRY(hipEventRecord(ev_post_done[k], post_stream));
         return H263MI_OK;
     }
 
@@ -684,7 +715,7 @@ static int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi
     b->pipeline_post = cfg && (cfg->flags & H263MI_CFG_PIPELINE_POST);
     if (cfg && (cfg->flags & H263MI_CFG_OVERLAP_POST) && !b->pipeline_post) {
         b->overlap_post = true;
-        if (hipStreamCreateWithFlags(&b->post_stream, hipStreamNonBlocking) != hipSuccess ||
+        if (fault_now() || hipStreamCreateWithFlags(&b->post_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_recon_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_post_done[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_post_done[1], hipEventDisableTiming) != hipSuccess)
@@ -863,21 +894,24 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
     }
     RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
     if (!d_rgba && !d_deblocked) return H263MI_OK;
-    return b->render(strength, d_rgba, d_deblocked);
+    return b->render(strength, d_rgba, d_deblocked, /*only_active=*/true);
 }
 
 /* the same with the coefficients as sparse events already in device memory (what the host entry points copy there) */
 int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
                                const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
-                               uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked)
+                               uint64_t coeff_pool_blocks, uint64_t n_events, uint8_t strength, uint8_t *d_rgba,
+                               uint8_t *d_deblocked)
 {
-    if (!b || !d_mbs || !d_block_first_event || !d_events || picture_type > H263MI_PICTURE_RESERVED || strength > 12)
+    if (!b || !d_mbs || !d_block_first_event || !d_events || picture_type > H263MI_PICTURE_RESERVED || strength > 12 ||
+        n_events > 0xffffffffull)
         return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     b->coeff_checked = coeff_pool_blocks != 0;
     b->coeff_pool_blocks = coeff_pool_blocks;
     b->cur_first_event = d_block_first_event;
     b->cur_events = d_events;
+    b->cur_n_events = (uint32_t)n_events;
     if (b->pipeline_post) {
         RC_TRY(b->submit(picture_type, d_mbs, nullptr, d_coeff_base, /*with_post=*/b->pending.valid));
         b->note_pending(strength, d_rgba, d_deblocked);
@@ -885,7 +919,7 @@ int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263
     }
     RC_TRY(b->submit(picture_type, d_mbs, nullptr, d_coeff_base));
     if (!d_rgba && !d_deblocked) return H263MI_OK;
-    return b->render(strength, d_rgba, d_deblocked);
+    return b->render(strength, d_rgba, d_deblocked, /*only_active=*/true);
 }
 
 }  // extern "C"
@@ -1004,16 +1038,18 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         // kernel of its own (k_expand) rebuild dense blocks in HBM first
         b->cur_first_event = g2.d_events;
         b->cur_events = g2.d_events + blocks + 1;
+        b->cur_n_events = (uint32_t)n_ev;
     } else if (blocks) {
         HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
     }
     b->coeff_pool_blocks = blocks;
     b->coeff_checked = true;
     RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types));
+    // ---- the launch is queued and the streams have advanced: nothing below may turn that into an error
     // (timing: the bracket ends right behind the launch -- closed at the next call it would hold the time the device
     // idles while the host parses the next pictures)
-    RC_TRY(b->time_close());
-    HIP_TRY(hipEventRecord(g2.done, b->stream));
+    (void)b->time_close();
+    if (hipEventRecord(g2.done, b->stream) != hipSuccess) (void)hipStreamSynchronize(b->stream);   // (the slot is reused two calls on)
     b->host_slot++;
     if (b->trace_host) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -1070,8 +1106,19 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
 {
     if (!b || !data || !len || strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
     const uint32_t n = b->n;
-    for (uint32_t i = 0; i < n; i++)
-        if (!data[i] && (len[i] || !stream_rc)) return H263MI_ERR_INVALID_ARGUMENT;
+    // data[i] == NULL: in the _ex form (stream_rc given) the stream has no picture in this call; in the plain form every
+    // stream decodes, and NULL with length 0 is an empty reader (the parser answers with its end-of-stream error, as it does
+    // for a non-NULL pointer with length 0 in either form)
+    static const uint8_t kEmptyReader[1] = {0};
+    std::vector<const uint8_t *> data_fixed;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!data[i] && len[i]) return H263MI_ERR_INVALID_ARGUMENT;
+        if (!data[i] && !stream_rc) {
+            if (data_fixed.empty()) data_fixed.assign(data, data + n);
+            data_fixed[i] = kEmptyReader;
+        }
+    }
+    if (!data_fixed.empty()) data = data_fixed.data();
     if (b->parser_ctx.size() != n) b->parser_ctx.assign(n, bits::ParserContext());
     if (b->parsed.size() != n) b->parsed.resize(n);
     // The records are parsed straight into the pinned staging slot this call will copy from (stream i at i * mbs per
@@ -1155,17 +1202,21 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     const bool deferred = b->pipeline_post && (d_rgba || d_deblocked);
     int rc = batch_submit_host(b, H263MI_PICTURE_P, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
                                n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred);
+    int render_rc = H263MI_OK;
     if (rc == H263MI_OK) {
+        // the pictures are decoded: what the streams remember of their headers moves on with them, whatever happens to the
+        // rendering below (a failed rendering is reported, but it does not un-decode anything)
+        for (uint32_t i = 0; i < n; i++) {
+            if (!takes_part[i]) continue;
+            b->parser_ctx[i] = b->parsed[i].next;
+            if (consumed) consumed[i] = b->parsed[i].bits_consumed / 8;      // reader.commit() drains whole bytes
+        }
         if (deferred) b->note_pending(strength, d_rgba, d_deblocked);
-        else if (d_rgba || d_deblocked) rc = b->render(strength, d_rgba, d_deblocked);
+        else if (d_rgba || d_deblocked) render_rc = b->render(strength, d_rgba, d_deblocked, /*only_active=*/true);
     }
     for (uint32_t i = 0; i < n; i++) b->ss[i].active = was_active[i] != 0;
     RC_TRY(rc);
-    for (uint32_t i = 0; i < n; i++) {
-        if (!takes_part[i]) continue;
-        b->parser_ctx[i] = b->parsed[i].next;
-        if (consumed) consumed[i] = b->parsed[i].bits_consumed / 8;          // reader.commit() drains whole bytes
-    }
+    RC_TRY(render_rc);
     return stream_rc ? H263MI_OK : first_error;
 }
 
@@ -1381,14 +1432,16 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
 
     DeviceGuard g(s->cfg.device_id);
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    // A picture of another size gets a frame store of its own.  The old one -- the state's last picture -- is given up only
+    // once the new picture's launch has been queued: everything from here to there can fail (allocations, copies, the
+    // launch), and the reference mutates its state after the last fallible call only (state.rs:464-487).
+    std::unique_ptr<h263mi_batch> fresh;
     if (!same_size) {
         h263mi_batch *nb = nullptr;
         RC_TRY(batch_create(1, L.width, L.height, &s->cfg, &nb));
-        delete s->b;
-        s->b = nb;
-        s->has_last = false;
+        fresh.reset(nb);
     }
-    h263mi_batch *b = s->b;
+    h263mi_batch *b = same_size ? s->b : fresh.get();
     h263mi_state::Staging &g2 = s->stg[s->next_slot & 1];
     const size_t event_words = sparse ? n_coeff_blocks + 1 + n_events : 0;
     RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1, event_words));
@@ -1409,6 +1462,7 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
         HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
         b->cur_first_event = g2.d_events;        // (read by the reconstruction waves themselves)
         b->cur_events = g2.d_events + n_coeff_blocks + 1;
+        b->cur_n_events = (uint32_t)n_events;
     } else if (n_coeff_blocks) {
         memcpy(g2.h_coeffs, coeffs, n_coeff_blocks * 128);
         HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, n_coeff_blocks * 128, hipMemcpyHostToDevice, b->stream));
@@ -1417,7 +1471,12 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
     b->coeff_pool_blocks = n_coeff_blocks;
     b->coeff_checked = true;
     RC_TRY(b->submit(desc->picture_type, g2.d_mbs, g2.d_coeffs, nullptr));
-    HIP_TRY(hipEventRecord(g2.done, b->stream));
+    // ---- the launch is queued: from here on nothing fails any more, the state changes (state.rs:464-483)
+    if (fresh) {
+        delete s->b;
+        s->b = fresh.release();
+    }
+    if (hipEventRecord(g2.done, b->stream) != hipSuccess) (void)hipStreamSynchronize(b->stream);   // (the slot is reused two pictures on)
     s->next_slot++;
     s->last_desc = *desc;
     s->has_last = true;
@@ -1536,6 +1595,24 @@ int h263mi_render_rgba(const h263mi_state *cs, uint8_t strength, uint8_t *rgba)
     }
     RC_TRY(b->render(strength, s->d_rgba, nullptr));
     HIP_TRY(hipMemcpyAsync(rgba, s->d_rgba, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return H263MI_OK;
+}
+
+int h263mi_render_rgba_pinned(const h263mi_state *cs, uint8_t strength, uint8_t *rgba_pinned)
+{
+    h263mi_state *s = const_cast<h263mi_state *>(cs);
+    if (!s || !rgba_pinned) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!s->has_last || !s->b) return H263MI_ERR_NO_PICTURE;
+    DeviceGuard g(s->cfg.device_id);
+    h263mi_batch *b = s->b;
+    // the device's view of the caller's page-locked buffer: the kernel stores RGBA straight into it
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, rgba_pinned, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        return H263MI_ERR_INVALID_ARGUMENT;          // not from h263mi_host_alloc / h263mi_host_register
+    }
+    RC_TRY(b->render(strength, static_cast<uint8_t *>(dev), nullptr));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return H263MI_OK;
 }
@@ -1711,6 +1788,49 @@ int h263mi_device_memcpy_d2h(int device_id, void *dst, const void *src, size_t b
     RC_TRY(check_device(device_id));
     DeviceGuard g(device_id);
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return H263MI_OK;
+}
+
+int h263mi_debug_fail_nth_hip_call(int n)
+{
+    if (n > 0) {
+        g_fail_countdown.store(n, std::memory_order_relaxed);
+        return n;
+    }
+    const int left = g_fail_countdown.exchange(-1, std::memory_order_relaxed);
+    return left < 0 ? 0 : left;
+}
+
+int h263mi_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return H263MI_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return H263MI_ERR_NO_DEVICE;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped));
+    return H263MI_OK;
+}
+
+int h263mi_host_free(void *p)
+{
+    if (!p) return H263MI_OK;
+    HIP_TRY(hipHostFree(p));
+    return H263MI_OK;
+}
+
+int h263mi_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return H263MI_ERR_INVALID_ARGUMENT;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return H263MI_ERR_NO_DEVICE;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return H263MI_OK;
+}
+
+int h263mi_host_unregister(void *p)
+{
+    if (!p) return H263MI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipHostUnregister(p));
     return H263MI_OK;
 }
 

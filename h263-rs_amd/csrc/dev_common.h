@@ -133,6 +133,8 @@ struct ReconArgs {
     uint32_t tiles_x, tiles_y;
     uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x): tile / tiles_x == mul_hi(tile, inv_tiles_x) (set by the launcher)
     uint32_t bands;              // k_recon: XCDs that share one picture (8 or 4; set by the launcher, see launch_frame)
+    uint32_t n_events;           // sparse transport: words in `events` (0xffffffff: the caller did not say) -- a block whose
+                                 // bounds are not ascending or reach beyond it is not read and the picture is rejected
 };
 
 // ---------------------------------------------------------------------------

@@ -738,13 +738,24 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
     if (stage < 0 || stage == 0) *reinterpret_cast<uint4 *>(dense + lane * 8) = make_uint4(0, 0, 0, 0);
     if (stage < 0 || stage == 1) {
         uint32_t at = 0, end = 0;
+        bool bad = false;
         if (has) {
             const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
             // (the first round's bounds were requested by the fetch phase)
-            const uint32_t first = bounds_known ? known_first : fe[0], count = (bounds_known ? known_next : fe[1]) - first;
+            const uint32_t first = bounds_known ? known_first : fe[0], next = bounds_known ? known_next : fe[1];
+            // The bounds come out of device memory nobody may have validated (h263mi_batch_decode_events): a pair that is
+            // not ascending, or that reaches beyond the events the caller said there are, reads NOTHING and rejects the
+            // picture (a.n_events = 0xffffffff when the caller did not say: only the order is checked then).
+            bad = first > next || next > a.n_events;
+            const uint32_t count = bad ? 0u : next - first;
             at = first + (uint32_t)r;
             end = first + (count > 64u ? 64u : count);          // (a block has 64 positions)
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        recon_report(a, lane, p.pic, false, __ballot(bad) != 0);
+#else
+        if (bad) a.status[p.pic] |= STATUS_COEFF_INDEX_OUT_OF_RANGE;
+#endif
         wave_fence();                                           // zeroed before the first LEVEL lands
 #if defined(__HIP_DEVICE_COMPILE__)
         while (__ballot(at < end) != 0) {

@@ -73,6 +73,8 @@ EXPORTS = [
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
     "h263mi_synth_picture_host", "h263mi_synth_batch_device",
+    "h263mi_render_rgba_pinned", "h263mi_host_alloc", "h263mi_host_free", "h263mi_host_register", "h263mi_host_unregister",
+    "h263mi_debug_fail_nth_hip_call",
 ]
 
 
@@ -152,7 +154,13 @@ def lib():
         L.h263mi_batch_mbs_per_picture.restype = u32
         L.h263mi_batch_submit.argtypes = [vp, u8, vp, vp, vp]
         L.h263mi_batch_decode.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp]
-        L.h263mi_batch_decode_events.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, u8, vp, vp]
+        L.h263mi_batch_decode_events.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8, vp, vp]
+        L.h263mi_render_rgba_pinned.argtypes = [vp, u8, vp]
+        L.h263mi_host_alloc.argtypes = [sz, C.POINTER(vp)]
+        L.h263mi_host_free.argtypes = [vp]
+        L.h263mi_host_register.argtypes = [vp, sz]
+        L.h263mi_host_unregister.argtypes = [vp]
+        L.h263mi_debug_fail_nth_hip_call.argtypes = [i32]
         L.h263mi_batch_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32]
         L.h263mi_batch_decode_next_pictures_ex.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp]
         L.h263mi_batch_sync_streams.argtypes = [vp, vp]
@@ -349,6 +357,53 @@ class H263State:
         _check(lib().h263mi_render_rgba(self._h, strength, _p(out)), "render_rgba")
         return out
 
+    def render_rgba_pinned(self, strength, pinned):
+        """h263mi_render_rgba_pinned: RGBA of the last picture straight into the caller's page-locked buffer (a PinnedBuffer
+        or a registered numpy array); returns a view of the w*h*4 bytes"""
+        v = self._view(lib().h263mi_get_last_picture, "get_last_picture")
+        if v is None:
+            raise H263Error(ERR_NO_PICTURE, "render_rgba_pinned")
+        arr = pinned.array if isinstance(pinned, PinnedBuffer) else pinned
+        n = v.width * v.height * 4
+        assert arr.nbytes >= n
+        _check(lib().h263mi_render_rgba_pinned(self._h, strength, _p(arr)), "render_rgba_pinned")
+        return arr[:n]
+
+
+class PinnedBuffer:
+    """page-locked, device-visible host memory (h263mi_host_alloc) as a numpy uint8 array"""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(lib().h263mi_host_alloc(nbytes, C.byref(p)), "host_alloc")
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().h263mi_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def host_register(arr):
+    _check(lib().h263mi_host_register(_p(arr), arr.nbytes), "host_register")
+
+
+def host_unregister(arr):
+    _check(lib().h263mi_host_unregister(_p(arr)), "host_unregister")
+
+
+def debug_fail_nth_hip_call(n):
+    """TEST HOOK: the n-th HIP call of the host entry points from now on fails (0 = off); returns calls still to go"""
+    return lib().h263mi_debug_fail_nth_hip_call(n)
+
 
 def synchronize(device_id=0):
     _check(lib().h263mi_device_synchronize(device_id), "device_synchronize")
@@ -420,10 +475,11 @@ class Batch:
                                          d_rgba, d_deblocked), "batch_decode")
 
     def decode_events(self, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base=None, coeff_pool_blocks=0,
-                      strength=0, d_rgba=None, d_deblocked=None):
-        """h263mi_batch_decode_events: decode with the coefficients as sparse events in device memory"""
+                      strength=0, d_rgba=None, d_deblocked=None, n_events=0):
+        """h263mi_batch_decode_events: decode with the coefficients as sparse events in device memory (n_events: words in
+        d_events, 0 = not told: then the device only checks that a block's bounds ascend)"""
         _check(lib().h263mi_batch_decode_events(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
-                                                coeff_pool_blocks, strength, d_rgba, d_deblocked), "batch_decode_events")
+                                                coeff_pool_blocks, n_events, strength, d_rgba, d_deblocked), "batch_decode_events")
 
     def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None):
         """one coded picture per stream (bytes-like objects) through the host parser threads and the GPU; returns the
@@ -437,9 +493,12 @@ class Batch:
     def prepare_pictures(self, data_list):
         """(None entries: the stream has no picture in the call -- decode_next_pictures_ex only)"""
         assert len(data_list) == self.n
-        keep = [np.frombuffer(bytes(d), dtype=np.uint8) if d is not None else np.zeros(0, np.uint8) for d in data_list]
-        pd = (C.c_void_p * self.n)(*[k.ctypes.data if k.size else None for k in keep])
-        ln = (C.c_size_t * self.n)(*[k.size for k in keep])
+        # an EMPTY picture (b"") is not "no picture": it goes to the parser and gets its end-of-stream error, so it
+        # travels as a non-NULL pointer with length 0; only None becomes NULL
+        empty = np.zeros(1, np.uint8)
+        keep = [(np.frombuffer(bytes(d), dtype=np.uint8) if len(d) else empty) if d is not None else None for d in data_list]
+        pd = (C.c_void_p * self.n)(*[k.ctypes.data if k is not None else None for k in keep])
+        ln = (C.c_size_t * self.n)(*[(len(d) if d is not None else 0) for d in data_list])
         return pd, ln, keep
 
     def decode_next_pictures_ex(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define H263MI_ABI_VERSION 3
+#define H263MI_ABI_VERSION 4
 
 /* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
 #define H263MI_OK                                  0
@@ -236,6 +236,20 @@ int h263mi_copy_yuv(const h263mi_state *s, uint8_t *y, uint8_t *cb, uint8_t *cr)
  * not modified (post-filter, deblock.rs:1-2).
  */
 int h263mi_render_rgba(const h263mi_state *s, uint8_t strength, uint8_t *rgba);
+/*
+ * The same into PINNED host memory (ABI 4), for a caller that renders every picture: `rgba` must lie in memory from
+ * h263mi_host_alloc or registered with h263mi_host_register (else H263MI_ERR_INVALID_ARGUMENT).  The kernel's RGBA stores
+ * go straight over the link into that memory -- no device buffer, no second copy, no pageable staging inside the
+ * runtime -- and the call returns when they have landed.  What yuv420_to_rgba returns as a fresh Vec<u8> per frame
+ * (bt601.rs:128) is here a buffer the caller owns and reuses.
+ */
+int h263mi_render_rgba_pinned(const h263mi_state *s, uint8_t strength, uint8_t *rgba_pinned);
+/* page-locked, device-visible host memory for h263mi_render_rgba_pinned (and faster h263mi_copy_yuv / h263mi_render_rgba
+ * targets); h263mi_host_register pins memory the caller already owns (page granularity is the runtime's business). */
+int h263mi_host_alloc(size_t bytes, void **out);
+int h263mi_host_free(void *p);
+int h263mi_host_register(void *p, size_t bytes);
+int h263mi_host_unregister(void *p);
 
 /* ======================================================================= */
 /* deblock crate  (deblock/src/deblock.rs)                                  */
@@ -308,10 +322,15 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
  * block number; the array has one entry more than the pool has blocks), d_events holds `level << 16 | x + 8 * y` per
  * non-zero LEVEL (an intra block's DC travels in the record), at most 64 per block, every position at most once.  This
  * is the form the host parser emits and h263mi_batch_decode_next_pictures copies to the device: the reconstruction
- * waves read it as it is. */
+ * waves read it as it is.
+ * n_events (ABI 4): the number of words d_events holds, or 0 = not told.  The device arrays are the caller's and nobody
+ * has validated them; when n_events is given, a block whose bounds are not ascending or reach beyond it is NOT read and
+ * the stream's picture is rejected at the next sync (H263MI_ERR_INVALID_ARGUMENT, like a coded block outside the pool).
+ * With 0 the bounds are trusted (a descending pair still reads nothing). */
 int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
                                const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
-                               uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
+                               uint64_t coeff_pool_blocks, uint64_t n_events, uint8_t strength, uint8_t *d_rgba,
+                               uint8_t *d_deblocked);
 /* deblock (strength 0 = off) + BT.601 of every stream's last picture into d_rgba
  * (DEVICE, n_streams * w*h*4 bytes, stream-major); d_deblocked (DEVICE, may be NULL)
  * additionally receives the filtered planes, n_streams * (w*h + 2*cw*ch) bytes as
@@ -351,6 +370,9 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  * records straight into the pinned staging memory the copy to the device reads.  A batch is driven from one thread at a
  * time.  With H263MI_TRACE_E2E set in the environment the batch prints, when it is destroyed, where the host time of
  * these calls went (parser threads / waiting for a staging slot / packing / enqueueing).
+ * Every stream decodes in this form: data[s] == NULL is accepted only with len[s] == 0 and is an EMPTY reader (the stream
+ * gets the parser's end-of-stream error and, all or nothing, the call fails with it); "no picture for this stream" exists
+ * in the _ex form only.
  */
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads);
@@ -361,7 +383,8 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
  *                 H263MI_ERR_PICTURE_FORMAT_INVALID (not the batch's size), H263MI_ERR_UNCODED_IFRAME_BLOCKS (inter
  *                 macroblocks and no reference picture yet, gather.rs:149: found on the host, before anything is
  *                 queued).  A stream that fails keeps its state, parser state included (state.rs:142); the others advance.
- *   data[s] NULL  stream s has no picture in this call and is left alone (also: h263mi_batch_set_active).
+ *   data[s] NULL  stream s has no picture in this call and is left alone (also: h263mi_batch_set_active).  A non-NULL
+ *                 pointer with len[s] == 0 is an empty reader, not "no picture": the stream gets its parse error.
  *   d_rgba / d_deblocked (may be NULL)  deblock(strength) + BT.601 of the pictures just decoded, as h263mi_batch_decode
  *                 does it: on a H263MI_CFG_PIPELINE_POST batch deferred to the next call's launch (k_frame), else a launch
  *                 of its own behind the reconstruction.  Streams that did not decode a picture in this call are not
@@ -416,6 +439,11 @@ int h263mi_device_free(int device_id, void *p);
 int h263mi_device_memcpy_h2d(int device_id, void *dst, const void *src, size_t bytes);
 int h263mi_device_memcpy_d2h(int device_id, void *dst, const void *src, size_t bytes);
 int h263mi_device_synchronize(int device_id);
+/* TEST HOOK (tests/test_gpu_round4.py): the n-th HIP runtime call the host entry points make from now on (allocations,
+ * copies, event operations, launches; n >= 1) is not executed and fails as out-of-memory; 0 or negative switches the hook
+ * off.  Returns the calls still to go before the injected failure (<= 0: it has fired, or the hook is off).  Sweeping n
+ * over one call proves that an error at any point leaves the state as it was (state.rs:142). */
+int h263mi_debug_fail_nth_hip_call(int n);
 
 /* On-box memory ceiling of the device (bench support, BASELINE.md section 4 "measure an on-box copy-kernel
  * ceiling"): streams `bytes` through a streaming kernel `reps` times on cfg's stream, in each of a few launch shapes

@@ -55,6 +55,7 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
     a.coeffs = coeffs;
     a.block_first_event = block_first_event;
     a.events = events;
+    a.n_events = 0xffffffffu;                    // (the caller's arrays are built by the tests: only the order is checked)
     a.coeff_base = coeff_base;
     a.ref = ref ? ref : cur;
     a.cur = cur;

@@ -25,6 +25,8 @@ OK = 0
  ERR_PICTURE_FORMAT_INVALID, ERR_UNCODED_IFRAME_BLOCKS, ERR_UNHANDLED_IO_ERROR, ERR_UNIMPLEMENTED_DECODING) = range(-1, -18, -1)
 ERR_INVALID_ARGUMENT = -100
 ERR_NO_DEVICE = -101
+ERR_HIP = -102
+ERR_OUT_OF_MEMORY = -103
 ERR_NO_PICTURE = -104
 
 def events_from_dense(coeffs, intra_blocks=None):

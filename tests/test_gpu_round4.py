@@ -96,3 +96,255 @@ def test_the_bench_path_events_k_frame_64x1080p_every_picture(odd_start):
                 s, f, bad.size, divmod(int(bad[0]) // 4, W))
         assert_planes_equal(b.copy_yuv(s), ref, "last picture of stream %d" % s)
     b.close()
+
+
+def _upload(arr):
+    d = h263mi.DeviceBuffer(max(arr.nbytes, 16))
+    if arr.nbytes:
+        d.upload(arr)
+    return d
+
+
+# ---------------------------------------------------------------------------------------------
+# "on error the state is unchanged" (state.rs:142, 464-487) with a failure injected at EVERY HIP call a submit makes:
+# same size (the ping-pong must not lose the last picture) and a size change (the old frame store must survive until the
+# new picture's launch is queued -- round 3 gave it up before the allocations and copies that can fail)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("new_size", [(176, 144), (96, 80)])
+def test_a_failure_at_any_hip_call_leaves_the_state_unchanged(new_size):
+    import recgen
+    w0, h0 = 176, 144
+    st = h263mi.H263State()
+    m0, c0 = recgen.intra_picture(w0, h0, seed=3)
+    st.submit_picture(w0, h0, m0, c0, h263mi.PICTURE_I, temporal_reference=7, pquant=9)
+    rc, want0 = orc.decode_picture(w0, h0, m0, c0, None)
+    assert rc == 0
+    rgba0 = _rgba_want(want0, 5, w0)
+    w1, h1 = new_size
+    same = (w1, h1) == (w0, h0)
+    if same:                       # a P picture on top of the I picture
+        m1, c1 = recgen.inter_picture(w1, h1, seed=4, mv_range=30, p_4v=0.2, p_coded=0.5, quant=8)
+        ptype, ref = h263mi.PICTURE_P, want0
+    else:                          # another size: legal as an I picture (state.rs:157-176)
+        m1, c1 = recgen.intra_picture(w1, h1, seed=5)
+        ptype, ref = h263mi.PICTURE_I, None
+    rc, want1 = orc.decode_picture(w1, h1, m1, c1, ref)
+    assert rc == 0
+    failures = 0
+    for nth in range(1, 200):
+        h263mi.debug_fail_nth_hip_call(nth)
+        try:
+            st.submit_picture(w1, h1, m1, c1, ptype, temporal_reference=8, pquant=8)
+            fired = h263mi.debug_fail_nth_hip_call(0) <= 0
+            assert not fired, "the %d-th HIP call failed and the submit reported success" % nth
+            break                                              # the call needs fewer than nth HIP calls: it went through
+        except h263mi.H263Error as e:
+            assert e.code in (h263mi.ERR_OUT_OF_MEMORY,), (nth, e.code)
+            h263mi.debug_fail_nth_hip_call(0)
+            failures += 1
+        # the previous picture is still the last picture: header, planes, and it still renders
+        pic = st.get_last_picture()
+        assert pic is not None, "failure at HIP call %d: the state lost its last picture" % nth
+        assert (pic.width, pic.height) == (w0, h0) and pic.temporal_reference == 7
+        assert_planes_equal(pic.as_yuv(), want0, "after a failure at HIP call %d" % nth)
+        assert (st.render_rgba(5) == rgba0).all()
+    else:
+        pytest.fail("the submit never went through")
+    assert failures >= (6 if not same else 3), failures          # allocations, copies, the launch: all were hit
+    pic = st.get_last_picture()
+    assert (pic.width, pic.height) == (w1, h1) and pic.temporal_reference == 8
+    assert_planes_equal(pic.as_yuv(), want1, "the picture that finally went through")
+    st.close()
+
+
+def test_failure_injection_in_the_batch_parser_entry_keeps_every_stream():
+    """h263mi_batch_decode_next_pictures_ex with a failure at each HIP call of the call: either nothing changed for any
+    stream (parser state included: the same data decodes afterwards) or the call went through"""
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    w, h, n, q = 176, 144, 4, 6
+    b = h263mi.Batch(n, w, h, pipeline_post=True)
+    refs = [None] * n
+
+    def pictures(f, intra):
+        datas, recs = [], []
+        for s in range(n):
+            if intra:
+                mbs, co = recgen.intra_picture(w, h, seed=77 * f + s, max_level=60)
+                mbs = make_codable(mbs, q, s, 0)
+            else:
+                mbs, co = recgen.inter_picture(w, h, seed=77 * f + s, mv_range=32, p_4v=0.2, p_coded=0.4, quant=q, max_level=60)
+                mbs = make_codable(mbs, q, s + f, 1)
+            datas.append(enc.encode_picture(w, h, 0 if intra else 1, q, mbs, co, temporal_reference=f))
+            recs.append((mbs, co))
+        return datas, recs
+
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+    datas, recs = pictures(0, True)
+    used, rcs = b.decode_next_pictures_ex(datas, n_threads=2, strength=5, d_rgba=d_rgba.ptr)
+    assert not any(rcs)
+    for s in range(n):
+        rc, refs[s] = orc.decode_picture(w, h, recs[s][0], recs[s][1], None)
+    b.sync()
+    datas, recs = pictures(1, False)
+    failures = 0
+    for nth in range(1, 100):
+        h263mi.debug_fail_nth_hip_call(nth)
+        try:
+            used, rcs = b.decode_next_pictures_ex(datas, n_threads=2, strength=5, d_rgba=d_rgba.ptr)
+            fired = h263mi.debug_fail_nth_hip_call(0) <= 0
+            if fired:                                           # a failure behind the point of no return is not reported
+                pass
+            assert not any(rcs)
+            break
+        except h263mi.H263Error:
+            h263mi.debug_fail_nth_hip_call(0)
+            failures += 1
+            b.sync()
+            for s in range(n):
+                assert_planes_equal(b.copy_yuv(s), refs[s], "stream %d after a failure at HIP call %d" % (s, nth))
+    else:
+        pytest.fail("the call never went through")
+    assert failures >= 3
+    b.sync()
+    for s in range(n):
+        rc, refs[s] = orc.decode_picture(w, h, recs[s][0], recs[s][1], refs[s])
+        assert_planes_equal(b.copy_yuv(s), refs[s], "stream %d after the call went through" % s)
+        assert (d_rgba.download(w * h * 4, s * w * h * 4) == _rgba_want(refs[s], 5, w)).all()
+    b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in caller's surface: decode_next_picture + RGBA into the caller's pinned buffer (no device buffer, no pageable
+# copy): bit-exact, for allocated and for registered memory; pageable memory is refused
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(176, 144), (1920, 1080), (100, 60)])
+def test_render_rgba_pinned_matches_the_oracle(w, h):
+    import recgen
+    st = h263mi.H263State()
+    pinned = h263mi.PinnedBuffer(w * h * 4 + 64)
+    ref = None
+    for f, strength in enumerate((0, 5, 12)):
+        if f == 0:
+            mbs, co = recgen.intra_picture(w, h, seed=f + 1)
+        else:
+            mbs, co = recgen.inter_picture(w, h, seed=f + 1, mv_range=30, p_4v=0.2, p_coded=0.4, quant=7)
+        st.submit_picture(w, h, mbs, co, h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, temporal_reference=f)
+        rc, ref = orc.decode_picture(w, h, mbs, co, ref)
+        assert rc == 0
+        pinned.array[:] = 0x5a
+        got = st.render_rgba_pinned(strength, pinned)
+        assert (got == _rgba_want(ref, strength, w)).all(), (f, strength)
+        assert (pinned.array[w * h * 4:] == 0x5a).all()           # nothing beyond the picture was written
+        assert (st.render_rgba(strength) == got).all()            # the pageable form agrees
+    # memory the caller owns, registered
+    mine = np.zeros(w * h * 4 + 4096, np.uint8)
+    h263mi.host_register(mine)
+    got = st.render_rgba_pinned(12, mine)
+    assert (got == _rgba_want(ref, 12, w)).all()
+    h263mi.host_unregister(mine)
+    with pytest.raises(h263mi.H263Error) as e:
+        st.render_rgba_pinned(12, np.zeros(w * h * 4, np.uint8))  # pageable: refused, not copied behind the caller's back
+    assert e.value.code == h263mi.ERR_INVALID_ARGUMENT
+    pinned.free()
+    st.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# ADVICE r3: a decode call renders only the streams that decoded (non-pipelined batches too); an EMPTY picture is not "no
+# picture"; device-resident event bounds are checked against n_events
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_a_stream_that_sits_a_call_out_keeps_its_rgba(pipeline):
+    import recgen
+    w, h, n = 96, 64, 4
+    b = h263mi.Batch(n, w, h, pipeline_post=pipeline)
+    d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+    refs = [None] * n
+
+    def submit(f, intra, skip=None):
+        mbs_all, co_all, base, at = [], [], [], 0
+        for s in range(n):
+            m, c = (recgen.intra_picture(w, h, seed=9 * f + s) if intra else
+                    recgen.inter_picture(w, h, seed=9 * f + s, mv_range=20, p_coded=0.5, quant=7))
+            if s != skip:
+                rc, refs[s] = orc.decode_picture(w, h, m, c, None if intra else refs[s])
+            mbs_all.append(m); co_all.append(c); base.append(at); at += len(c)
+        d = (_upload(np.concatenate(mbs_all)), _upload(np.concatenate(co_all) if at else np.zeros((1, 64), np.int16)),
+             _upload(np.array(base, np.uint64)))
+        b.decode(h263mi.PICTURE_I if intra else h263mi.PICTURE_P, d[0].ptr, d[1].ptr, d[2].ptr, max(at, 1), 5, d_rgba.ptr)
+        return d
+    keep = [submit(0, True)]
+    b.sync()
+    marker = np.full(w * h * 4, 0xA7, np.uint8)
+    d_rgba.upload(marker, 2 * w * h * 4)                          # stream 2's part of the output
+    b.set_active([s != 2 for s in range(n)])
+    keep.append(submit(1, False, skip=2))
+    b.sync()
+    got = d_rgba.download()
+    for s in range(n):
+        part = got[s * w * h * 4:(s + 1) * w * h * 4]
+        if s == 2:
+            assert (part == 0xA7).all(), "the RGBA of a stream that sat the call out was rewritten"
+        else:
+            assert (part == _rgba_want(refs[s], 5, w)).all(), s
+    b.set_active(None)
+    b.close()
+
+
+def test_empty_picture_is_an_error_and_none_is_no_picture():
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    w, h, n, q = 176, 144, 3, 6
+    b = h263mi.Batch(n, w, h)
+    datas = []
+    for s in range(n):
+        mbs, co = recgen.intra_picture(w, h, seed=s + 1, max_level=60)
+        datas.append(enc.encode_picture(w, h, 0, q, make_codable(mbs, q, s, 0), co, temporal_reference=0))
+    used, rcs = b.decode_next_pictures_ex([datas[0], b"", None], n_threads=1)
+    assert rcs[0] == 0 and rcs[1] < 0 and rcs[2] == 0 and used[1] == 0 and used[2] == 0
+    assert b.stream_has_picture(0) and not b.stream_has_picture(1) and not b.stream_has_picture(2)
+    with pytest.raises(h263mi.H263Error):                       # plain form: every stream decodes, an empty reader fails the call
+        b.decode_next_pictures([datas[0], b"", datas[2]], n_threads=1)
+    b.close()
+
+
+def test_event_bounds_from_device_memory_are_checked_against_n_events():
+    import recgen
+    w, h, n = 96, 64, 2
+    b = h263mi.Batch(n, w, h)
+    mbs_all, firsts, evs, base, at_b, at_e = [], [], [], [], 0, 0
+    want = []
+    for s in range(n):
+        m, c = recgen.intra_picture(w, h, seed=40 + s)
+        rc, planes = orc.decode_picture(w, h, m, c, None)
+        want.append(planes)
+        intra_blocks = np.ones(len(c), bool)
+        first, ev = h263mi.events_from_dense(c, intra_blocks)
+        mbs_all.append(m); base.append(at_b)
+        firsts.append(first[:-1].astype(np.uint32) + at_e)
+        evs.append(ev); at_b += len(c); at_e += len(ev)
+    first_all = np.concatenate(firsts + [np.array([at_e], np.uint32)])
+    ev_all = np.concatenate(evs + [np.zeros(8, np.uint32)])
+    d = (_upload(np.concatenate(mbs_all)), _upload(first_all), _upload(ev_all), _upload(np.array(base, np.uint64)))
+    b.decode_events(h263mi.PICTURE_I, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, at_b, n_events=at_e)
+    assert b.sync_streams() == [0, 0]
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), want[s], "stream %d" % s)
+    # stream 1's last block claims events beyond the array: rejected, stream 0 unaffected
+    bad = first_all.copy()
+    bad[-1] = at_e + 1000
+    d_bad = _upload(bad)
+    b.decode_events(h263mi.PICTURE_I, d[0].ptr, d_bad.ptr, d[2].ptr, d[3].ptr, at_b, n_events=at_e)
+    assert b.sync_streams() == [0, h263mi.ERR_INVALID_ARGUMENT]
+    # a descending pair in stream 0: rejected even when n_events was not given
+    bad = first_all.copy()
+    bad[3] = bad[2] - 1 if bad[2] > 0 else 0
+    bad[2] = bad[3] + 5
+    d_bad2 = _upload(bad)
+    b.decode_events(h263mi.PICTURE_I, d[0].ptr, d_bad2.ptr, d[2].ptr, d[3].ptr, at_b)
+    rcs = b.sync_streams()
+    assert rcs[0] == h263mi.ERR_INVALID_ARGUMENT and rcs[1] == 0
+    b.close()

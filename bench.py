@@ -485,6 +485,95 @@ def plain_function_latency(h263mi, reps=10):
     return out
 
 
+def single_stream_latency(h263mi, device_id, stream, n_p=12, reps=3):
+    """The drop-in caller's own number: ONE H263State, one picture at a time, as a Ruffle-style consumer runs it
+    (state.rs:138-141 decode_next_picture -> picture.rs:140-142 as_yuv -> deblock -> bt601.rs:105 yuv420_to_rgba): the
+    host-to-host latency per 1080p picture of h263mi_decode_next_picture + the RGBA rendering, for a key frame and for
+    P pictures shaped like real content, with the RGBA going to pageable memory (h263mi_render_rgba), to the caller's
+    pinned buffer through a device buffer and a copy (h263mi_render_rgba on pinned memory) and straight into the pinned
+    buffer (h263mi_render_rgba_pinned: the kernel's stores cross the link themselves).  Beside it: the C port of the
+    reference CPU path on one thread for the same pictures (reconstruction + deblock x 3 + BT.601, explicit-SIMD
+    post-processing; no bitstream parsing in it: the oracle has no parser), and this library's host parser alone."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    from oracle import oracle as orc
+    from oracle import native_bench
+    pics, recs = [], []
+    for f in range(1 + n_p):
+        if f == 0:
+            mbs, co = recgen.realistic_intra_picture(W, H, 900)
+        else:
+            mbs, co = recgen.realistic_inter_picture(W, H, 9000 + f)
+        mbs = make_codable(mbs, 10, f, 0 if f == 0 else 1)
+        pics.append(enc.encode_picture(W, H, 0 if f == 0 else 1, 10, mbs, co, temporal_reference=f))
+        recs.append((mbs, co))
+    st = h263mi.H263State(h263mi.SORENSON_SPARK_BITSTREAM, device_id, stream)
+    pinned = h263mi.PinnedBuffer(RGBA_BYTES)
+    pageable = np.empty(RGBA_BYTES, np.uint8)
+    lib = h263mi.lib()
+
+    def render(mode):
+        if mode == "pageable":
+            h263mi._check(lib.h263mi_render_rgba(st._h, STRENGTH, h263mi._p(pageable)), "render_rgba")
+            return pageable
+        if mode == "pinned_copy":
+            h263mi._check(lib.h263mi_render_rgba(st._h, STRENGTH, h263mi._p(pinned.array)), "render_rgba")
+            return pinned.array
+        return st.render_rgba_pinned(STRENGTH, pinned)
+
+    out, ok = {}, True
+    for mode in ("pageable", "pinned_copy", "pinned_direct"):
+        t_i, t_p, t_dec_i, t_dec_p = [], [], [], []
+        for rep_ in range(reps + 1):
+            st.reset()
+            for f, data in enumerate(pics):
+                t0 = time.perf_counter()
+                st.decode_next_picture(data)
+                t1 = time.perf_counter()
+                got = render(mode)
+                t2 = time.perf_counter()
+                if rep_:                                  # the first pass allocates staging and frame store
+                    (t_i if f == 0 else t_p).append(t2 - t0)
+                    (t_dec_i if f == 0 else t_dec_p).append(t1 - t0)
+        # parity of what was timed: the last picture of the chain, planes and RGBA
+        ref = None
+        for mbs, co in recs:
+            rc, ref = orc.decode_picture(W, H, mbs, co, ref)
+        filt = tuple(orc.deblock(p, pw, STRENGTH) for p, pw in zip(ref, (W, 960, 960)))
+        ok = ok and np.array_equal(np.asarray(got)[:RGBA_BYTES], orc.yuv420_to_rgba(*filt, W))
+        ok = ok and all(np.array_equal(g, e) for g, e in zip(st.get_last_picture().as_yuv(), ref))
+        med = lambda v: round(float(np.median(v)) * 1e3, 3)
+        out[mode] = {"I_picture_ms": med(t_i), "P_picture_ms": med(t_p), "P_picture_ms_p90": round(float(np.percentile(t_p, 90)) * 1e3, 3),
+                     "of_which_decode_call_ms": {"I": med(t_dec_i), "P": med(t_dec_p)}}
+    nb = native_bench.NativeOracle()
+    cw = 960
+    t_cpu_i, t_cpu_p = [], []
+    for rep_ in range(2):
+        ref = None
+        for f, (mbs, co) in enumerate(recs):
+            t0 = time.perf_counter()
+            rc, ref = orc.decode_picture(W, H, mbs, co, ref, L=nb.L)
+            filt = tuple(nb.deblock_simd(p, pw, STRENGTH) for p, pw in zip(ref, (W, cw, cw)))
+            nb.yuv420_to_rgba_simd(*filt, W)
+            (t_cpu_i if f == 0 else t_cpu_p).append(time.perf_counter() - t0)
+    st.close()
+    pinned.free()
+    out["cpu_port_one_thread"] = {"I_picture_ms": round(float(np.median(t_cpu_i)) * 1e3, 3),
+                                  "P_picture_ms": round(float(np.median(t_cpu_p)) * 1e3, 3),
+                                  "what": "C port of the reference CPU path (oracle, native build) from RECORDS: reconstruction + "
+                                          "deblock x 3 + BT.601 (explicit 128-bit SIMD forms), one thread, no bitstream parsing"}
+    out["parity_vs_oracle"] = "ok" if ok else "MISMATCH"
+    out["bytes_per_picture"] = {"I": len(pics[0]), "P_mean": int(sum(len(p) for p in pics[1:]) / n_p)}
+    out["what"] = ("one H263State, 1920x1080 Sorenson Spark pictures shaped like real content (1 I + %d P), one call of "
+                   "h263mi_decode_next_picture (host parse -> events -> H2D -> k_recon) + one RGBA rendering (deblock %d + BT.601) "
+                   "per picture, host to host, median of %d passes; pageable = h263mi_render_rgba into ordinary memory, "
+                   "pinned_copy = the same into h263mi_host_alloc memory, pinned_direct = h263mi_render_rgba_pinned" % (n_p, STRENGTH, reps))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def stub_main(args, rank, world):
     """CPU stand-in for the launcher test: same rendezvous, barrier and aggregation code over gloo, no GPU work."""
@@ -733,6 +822,7 @@ def main(argv=None):
         extra["e2e_bitstream"] = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba)
         extra["e2e_bitstream_realistic"] = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba, realistic=True)
         extra["plain_functions_1080p"] = plain_function_latency(h263mi)
+        extra["single_stream_1080p"] = single_stream_latency(h263mi, local_rank, stream)
 
     out = {
         "metric": "decoded megapixels/sec (IDCT+MC+YUV->RGB)",

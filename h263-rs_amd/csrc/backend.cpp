@@ -740,6 +740,7 @@ struct h263mi_state {
     h263mi_picture_desc last_desc{};
     bool has_last = false;
     bits::ParserContext parser_ctx;   // header + format of the last picture decoded from a bitstream (state.rs:143-167)
+    bits::ParsedPicture parsed;       // parse results of h263mi_decode_next_picture: kept, so that its buffers are reused
     // staging: two slots (pinned host + device) used alternately, so that filling slot i+1 on the host
     // overlaps the H2D copy and the kernel of slot i
     struct Staging {
@@ -815,7 +816,7 @@ static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n
 // (`first_event` + `events`, expanded on the device)
 static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
                           const int16_t *coeffs, size_t n_coeff_blocks, const uint32_t *first_event, const uint32_t *events,
-                          size_t n_events);
+                          size_t n_events, bool from_parser = false);
 
 extern "C" {
 
@@ -1387,12 +1388,14 @@ int h263mi_state_cleanup_buffers(h263mi_state *s)
 
 static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, const h263mi_mb_record *mbs, size_t n_mbs,
                           const int16_t *coeffs, size_t n_coeff_blocks, const uint32_t *first_event, const uint32_t *events,
-                          size_t n_events)
+                          size_t n_events, bool from_parser)
 {
+    // from_parser: the arrays are what bits::parse_picture just wrote -- valid by construction (quantisers, types, block
+    // indices, one event per position), so the per-record and per-event checks a caller's arrays get are skipped
     const bool sparse = first_event != nullptr;
     if (!s || !desc || (!mbs && n_mbs) || (!sparse && !coeffs && n_coeff_blocks) || (sparse && !events && n_events))
         return H263MI_ERR_INVALID_ARGUMENT;
-    if (sparse && n_coeff_blocks) {
+    if (sparse && n_coeff_blocks && !from_parser) {
         // offsets must be monotone and end at n_events: checked here, the kernel trusts them
         if (first_event[0] != 0 || first_event[n_coeff_blocks] != n_events) return H263MI_ERR_INVALID_ARGUMENT;
         // ... and a block's events name every position at most once (the device places them in no particular order)
@@ -1417,9 +1420,13 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
     bool any_inter = n_mbs < total;   // missing macroblocks are padded as Inter (state.rs:421-427)
     for (size_t i = 0; i < n_mbs; i++) {
         const h263mi_mb_record &m = mbs[i];
+        if (mb_is_inter(m.mb_type)) any_inter = true;
+        if (from_parser) {
+            if (any_inter) break;                // (nothing else to learn from a parser's records)
+            continue;
+        }
         if (m.mb_type > H263MI_MB_INTER4V_Q || m.quant < 1 || m.quant > 31 || (m.cbp & 0xC0) || (m.kill & 0xC0))
             return H263MI_ERR_INVALID_ARGUMENT;
-        if (mb_is_inter(m.mb_type)) any_inter = true;
         // (a record without coded blocks does not use its coeff_index)
         if (m.cbp && (size_t)m.coeff_index + (size_t)__builtin_popcount(m.cbp) > n_coeff_blocks) return H263MI_ERR_INVALID_ARGUMENT;
     }
@@ -1447,7 +1454,8 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
     RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1, event_words));
     HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
 
-    memcpy(g2.h_mbs, mbs, n_mbs * sizeof(MbRecord));
+    // (h263mi_decode_next_picture has its parser write the records straight into this slot)
+    if (n_mbs && mbs != g2.h_mbs) memcpy(g2.h_mbs, mbs, n_mbs * sizeof(MbRecord));
     for (size_t i = n_mbs; i < total; i++) {     // state.rs:421-427: Inter, mv (0,0), nothing coded
         MbRecord pad;
         memset(&pad, 0, sizeof pad);
@@ -1505,13 +1513,28 @@ int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len,
     if (!s || (!data && len)) return H263MI_ERR_INVALID_ARGUMENT;
     if (consumed) *consumed = 0;
     // serial half on the host (state.rs:143-427) ...
-    bits::ParsedPicture pic;
+    bits::ParsedPicture &pic = s->parsed;                // (kept between calls: no allocation per picture)
     pic.want_dense = false;                              // the coefficients travel as events
+    pic.mbs_ext = nullptr;
+    pic.mbs_ext_cap = 0;
+    if (s->b) {
+        // A stream rarely changes its size: the records are parsed straight into the pinned staging slot the next submit
+        // copies from (sized for the last picture; a picture with more macroblocks falls back to the parser's own array).
+        // The slot was last read by the copy of two pictures ago.
+        DeviceGuard g(s->cfg.device_id);
+        h263mi_state::Staging &g2 = s->stg[s->next_slot & 1];
+        const size_t total = (size_t)s->b->L.mbw * s->b->L.mbh;
+        if (g.ok && state_ensure_staging(g2, total, 1, 1) == H263MI_OK && hipEventSynchronize(g2.done) == hipSuccess) {
+            pic.mbs_ext = g2.h_mbs;
+            pic.mbs_ext_cap = total;
+        }
+    }
     RC_TRY(bits::parse_picture(data, len, s->options, &s->parser_ctx, pic));
     // ... everything from the cut line on (state.rs:421-483) on the GPU.  Nothing has touched the state so
     // far, so every error above leaves it unchanged, like the reader transaction of state.rs:142.
-    RC_TRY(h263mi_submit_picture_events(s, &pic.desc, pic.mbs.data(), pic.mbs.size(), pic.block_first_event.data(),
-                                        pic.n_coded_blocks, pic.events.data(), pic.events.size()));
+    if (pic.n_coded_blocks > 0xffffffffu / 8u) return H263MI_ERR_INVALID_ARGUMENT;
+    RC_TRY(submit_records(s, &pic.desc, pic.records(), pic.n_records(), nullptr, pic.n_coded_blocks, pic.block_first_event.data(),
+                          pic.events.data(), pic.events.size(), /*from_parser=*/true));
     s->parser_ctx = pic.next;
     if (consumed) *consumed = pic.bits_consumed / 8;     // reader.commit() drains whole bytes (reader.rs:391-394)
     return H263MI_OK;

@@ -543,7 +543,11 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
 
     if (INTERIOR || a.rgba) {
         // uniform 64-bit base of the picture + 32-bit lane offsets (w * h * 4 < 2^32: layout_fits)
+#if defined(H263MI_TIMING_RGBA_FOLD)
+        uint8_t *rgba = a.rgba;
+#else
         uint8_t *rgba = a.rgba + (size_t)pic * w * h * 4;
+#endif
         const int g = lane & 31, gx = INTERIOR ? xl + 4 * g : post_wrap_x(a, xl + 4 * g);
         // the lane's four pixels: all inside the picture (the only case away from the left / right picture edge),
         // or some of them (a picture whose width is not a multiple of 4), or none
@@ -578,7 +582,13 @@ H263_DEV void post_phase_store(const PostArgs &a, PostStrip &s, int lane, int sx
                     const ChromaTerms &t = (k < 2) ? t0 : t1;
                     px[k] = bt601_pack(gray + t.r, gray + t.g, gray + t.b);
                 }
+#if defined(H263MI_TIMING_RGBA_FOLD)
+                // TIMING EXPERIMENT ONLY (results wrong): every RGBA store of the launch lands in the first H263MI_TIMING_RGBA_FOLD
+                // bytes of the surface -- the store instructions, their lines and requests stay, the DRAM traffic goes
+                const uint32_t off = ((off0 + (rr ? row_bytes : 0u)) + (uint32_t)pic * 8294400u) & (uint32_t)(H263MI_TIMING_RGBA_FOLD - 1);
+#else
                 const uint32_t off = off0 + (rr ? row_bytes : 0u);
+#endif
 #if defined(H263MI_TIMING_NO_RGBA)
                 if (px[0] == 0x12345678u)                                  // TIMING EXPERIMENT ONLY: (almost) no RGBA store
 #endif

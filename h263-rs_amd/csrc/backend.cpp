@@ -164,6 +164,7 @@ void set_post_tiles(PostArgs &a)
 struct h263mi_batch {
     int device = 0;
     hipStream_t stream = nullptr;
+    static constexpr unsigned kPtrSlots = 4;
     // H263MI_CFG_OVERLAP_POST: k_post runs on a second stream so that the post-processing of picture i overlaps
     // the reconstruction of picture i+1 (k_recon is VALU-heavy, k_post store-heavy).  Legal with two frame sets:
     // post(i) reads set i; recon(i+1) reads set i and overwrites the set of picture i-1, which post(i-1) must have
@@ -179,8 +180,13 @@ struct h263mi_batch {
         bool valid = false;
         uint8_t strength = 0;
         uint8_t *rgba = nullptr, *planes = nullptr;
+        uint8_t *const *rgba_ptrs = nullptr;   // DEVICE array of per-stream output pointers (a batch inside a mixed-size set)
         std::vector<int8_t> set;               // per stream: frame set it reads, -1 = nothing to post-process
     } pending;
+    // per-stream output pointers for the kernels: ring of pinned host slots + device arrays, like the state words
+    uint8_t **h_ptrs = nullptr, **d_ptrs = nullptr;
+    hipEvent_t ptrs_copied[kPtrSlots] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned ptrs_slot = 0;
     uint32_t n = 0;
     FrameLayout L{};
     uint8_t *frames[2] = {nullptr, nullptr};   // ping-pong frame sets, n * frame_bytes each
@@ -313,6 +319,25 @@ struct h263mi_batch {
         return H263MI_OK;
     }
 
+    // hand the post-processing one output pointer per stream (host array of n DEVICE pointers): next ring slot + its copy
+    int push_rgba_ptrs(uint8_t *const *host_ptrs, uint8_t *const **d_out, hipStream_t on)
+    {
+        if (!h_ptrs) {
+            HIP_TRY(hipHostMalloc((void **)&h_ptrs, (size_t)n * kPtrSlots * sizeof(uint8_t *), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&d_ptrs, (size_t)n * kPtrSlots * sizeof(uint8_t *)));
+            for (hipEvent_t &e : ptrs_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const unsigned slot = ptrs_slot++ % kPtrSlots;
+        HIP_TRY(hipEventSynchronize(ptrs_copied[slot]));
+        uint8_t **h = h_ptrs + (size_t)slot * n, **d = d_ptrs + (size_t)slot * n;
+        memcpy(h, host_ptrs, (size_t)n * sizeof(uint8_t *));
+        RC_TRY(time_close());
+        HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(uint8_t *), hipMemcpyHostToDevice, on));
+        HIP_TRY(hipEventRecord(ptrs_copied[slot], on));
+        *d_out = d;
+        return H263MI_OK;
+    }
+
     int forget_pictures()
     {
         const int rc = flush_pending();        // what was asked to be rendered still is
@@ -361,6 +386,10 @@ struct h263mi_batch {
         if (h_status) (void)hipHostFree(h_status);
         if (d_state) (void)hipFree(d_state);
         if (h_state) (void)hipHostFree(h_state);
+        if (d_ptrs) (void)hipFree(d_ptrs);
+        if (h_ptrs) (void)hipHostFree(h_ptrs);
+        for (hipEvent_t e : ptrs_copied)
+            if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : state_copied)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -492,7 +521,8 @@ struct h263mi_batch {
         a.frame_set[1] = frames[1];
         PostArgs pa{};
         if (with_post) pa = post_args(0, pending.strength, pending.rgba, pending.planes);
-        const bool all_same = uniform() && (!with_post || (pending_uniform() && pending.set[0] >= 0));
+        if (with_post) pa.rgba_ptrs = pending.rgba_ptrs;       // (read in the per-stream branch of the kernel only)
+        const bool all_same = uniform() && (!with_post || (pending_uniform() && pending.set[0] >= 0 && !pending.rgba_ptrs));
         int out0 = 0;
         if (all_same) {
             const int cur = ss[0].cur;
@@ -571,16 +601,19 @@ struct h263mi_batch {
         return a;
     }
 
-    // k_post over `sets` (per stream: the frame set to read, -1 = skip the stream)
-    int launch_post_sets(const std::vector<int8_t> &sets, uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, hipStream_t on)
+    // k_post over `sets` (per stream: the frame set to read, -1 = skip the stream); rgba_ptrs: DEVICE array of per-stream
+    // output pointers instead of d_rgba (or nullptr)
+    int launch_post_sets(const std::vector<int8_t> &sets, uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, hipStream_t on,
+                         uint8_t *const *rgba_ptrs = nullptr)
     {
-        bool same = true, any = false;
+        bool same = rgba_ptrs == nullptr, any = false;
         for (int8_t v : sets) {
             same = same && v == sets[0];
             any = any || v >= 0;
         }
         if (!any) return H263MI_OK;
         PostArgs a = post_args(sets[0] >= 0 ? sets[0] : 0, strength, d_rgba, d_planes);
+        a.rgba_ptrs = rgba_ptrs;
         if (!same) {
             std::vector<uint32_t> words(n);
             for (uint32_t i = 0; i < n; i++)
@@ -597,14 +630,20 @@ struct h263mi_batch {
         return H263MI_OK;
     }
 
-    // pipeline mode: the post-processing of the pictures just submitted is deferred to the next launch
-    void note_pending(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes)
+    // pipeline mode: the post-processing of the pictures just submitted is deferred to the next launch.
+    // host_ptrs (or nullptr): n DEVICE pointers, the RGBA buffer of each stream (nullptr = none for it) instead of d_rgba.
+    int note_pending(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, uint8_t *const *host_ptrs = nullptr)
     {
-        pending.valid = d_rgba || d_planes;
+        pending.valid = false;
+        pending.rgba_ptrs = nullptr;
+        if (host_ptrs) RC_TRY(push_rgba_ptrs(host_ptrs, &pending.rgba_ptrs, stream));
+        pending.valid = d_rgba || d_planes || host_ptrs;
         pending.strength = strength;
         pending.rgba = d_rgba;
         pending.planes = d_planes;
-        for (uint32_t i = 0; i < n; i++) pending.set[i] = ss[i].active ? ss[i].cur : (int8_t)-1;
+        for (uint32_t i = 0; i < n; i++)
+            pending.set[i] = (ss[i].active && (!host_ptrs || host_ptrs[i])) ? ss[i].cur : (int8_t)-1;
+        return H263MI_OK;
     }
 
     // the deferred post-processing of pipeline mode, as a launch of its own
@@ -612,13 +651,13 @@ struct h263mi_batch {
     {
         if (!pending.valid) return H263MI_OK;
         pending.valid = false;
-        return launch_post_sets(pending.set, pending.strength, pending.rgba, pending.planes, stream);
+        return launch_post_sets(pending.set, pending.strength, pending.rgba, pending.planes, stream, pending.rgba_ptrs);
     }
 
     // only_active: the rendering half of a decode call -- streams that sat the call out (h263mi_batch_set_active, no data,
     // a picture that failed to parse) keep their part of the output buffers untouched, as the pipelined form (note_pending)
     // does; h263mi_batch_render_rgba renders every stream's last picture.
-    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, bool only_active = false)
+    int render(uint8_t strength, uint8_t *d_rgba, uint8_t *d_planes, bool only_active = false, uint8_t *const *host_ptrs = nullptr)
     {
         if (!any_picture()) return H263MI_ERR_NO_PICTURE;
         if (strength > 12) return H263MI_ERR_INVALID_ARGUMENT;
@@ -626,11 +665,13 @@ struct h263mi_batch {
         std::vector<int8_t> sets(n);
         bool reads[2] = {false, false};
         for (uint32_t i = 0; i < n; i++) {
-            sets[i] = (only_active && !ss[i].active) ? (int8_t)-1 : ss[i].cur;
+            sets[i] = ((only_active && !ss[i].active) || (host_ptrs && !host_ptrs[i])) ? (int8_t)-1 : ss[i].cur;
             if (sets[i] >= 0) reads[sets[i]] = true;
         }
         if (overlap_post) HIP_TRY(hipStreamWaitEvent(post_stream, ev_recon_done, 0));
-        RC_TRY(launch_post_sets(sets, strength, d_rgba, d_planes, stream_of(1)));
+        uint8_t *const *d_out_ptrs = nullptr;
+        if (host_ptrs) RC_TRY(push_rgba_ptrs(host_ptrs, &d_out_ptrs, stream_of(1)));
+        RC_TRY(launch_post_sets(sets, strength, d_rgba, d_planes, stream_of(1), d_out_ptrs));
         // a later reconstruction may overwrite a frame set only when every post-processing that reads it is done: streams
         // that have drifted apart read both sets
         if (overlap_post)
@@ -890,8 +931,7 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_r
         // this picture's reconstruction and the previous picture's post-processing in one launch; this picture's
         // post-processing waits for the next call (or the next sync)
         RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base, /*with_post=*/b->pending.valid));
-        b->note_pending(strength, d_rgba, d_deblocked);
-        return H263MI_OK;
+        return b->note_pending(strength, d_rgba, d_deblocked);
     }
     RC_TRY(b->submit(picture_type, d_mbs, d_coeffs, d_coeff_base));
     if (!d_rgba && !d_deblocked) return H263MI_OK;
@@ -915,8 +955,7 @@ int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263
     b->cur_n_events = (uint32_t)n_events;
     if (b->pipeline_post) {
         RC_TRY(b->submit(picture_type, d_mbs, nullptr, d_coeff_base, /*with_post=*/b->pending.valid));
-        b->note_pending(strength, d_rgba, d_deblocked);
-        return H263MI_OK;
+        return b->note_pending(strength, d_rgba, d_deblocked);
     }
     RC_TRY(b->submit(picture_type, d_mbs, nullptr, d_coeff_base));
     if (!d_rgba && !d_deblocked) return H263MI_OK;
@@ -980,6 +1019,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     // packing is a host memcpy of every record byte: a few threads, or one core caps the rate below the PCIe link
     auto pack = [&](uint32_t first, uint32_t last) {
         for (uint32_t i = first; i < last; i++) {
+            if (!b->ss[i].active) continue;      // sits the call out: its records are never read (STREAM_RECON_SKIP)
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
             for (uint32_t k = 0; k < n_mbs[i] && !from_parser; k++) {   // the same checks as h263mi_submit_picture
                 const MbRecord &m = mbs[i][k];
@@ -1030,7 +1070,15 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
     const auto t_enq0 = std::chrono::steady_clock::now();
     RC_TRY(b->time_close());                     // the copies below are not part of any kernel's time
-    HIP_TRY(hipMemcpyAsync(g2.d_mbs, g2.h_mbs, (size_t)b->n * per * sizeof(MbRecord), hipMemcpyHostToDevice, b->stream));
+    // the records of the streams that take part, one copy per run of neighbouring streams (all of them: one copy)
+    for (uint32_t i = 0; i < b->n;) {
+        if (!b->ss[i].active) { i++; continue; }
+        uint32_t j = i + 1;
+        while (j < b->n && b->ss[j].active) j++;
+        HIP_TRY(hipMemcpyAsync(g2.d_mbs + (size_t)i * per, g2.h_mbs + (size_t)i * per, (size_t)(j - i) * per * sizeof(MbRecord),
+                               hipMemcpyHostToDevice, b->stream));
+        i = j;
+    }
     HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     if (sparse && blocks) {
         h_first[blocks] = (uint32_t)n_ev;
@@ -1212,7 +1260,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
             b->parser_ctx[i] = b->parsed[i].next;
             if (consumed) consumed[i] = b->parsed[i].bits_consumed / 8;      // reader.commit() drains whole bytes
         }
-        if (deferred) b->note_pending(strength, d_rgba, d_deblocked);
+        if (deferred) render_rc = b->note_pending(strength, d_rgba, d_deblocked);
         else if (d_rgba || d_deblocked) render_rc = b->render(strength, d_rgba, d_deblocked, /*only_active=*/true);
     }
     for (uint32_t i = 0; i < n; i++) b->ss[i].active = was_active[i] != 0;
@@ -1341,6 +1389,265 @@ int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out)
     b->ev_ranges.clear();
     b->ev_used = 0;
     return H263MI_OK;
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// streams of DIFFERENT picture sizes behind one call (h263mi_mixed_*)
+//
+// The reference resolves the picture format per H263State and per picture (state.rs:157-176): a server holds QCIF, CIF
+// and 1080p streams side by side, and a stream may change its size at an I picture.  A fixed-geometry batch (above)
+// takes one size; h263mi_mixed keeps one such batch per size CLASS -- created when the first stream of that size
+// shows up, n slots each, slot = stream index -- and a call decodes every class that has pictures in it with ONE launch
+// (k_frame on pipelined classes), back to back on the same HIP stream.  A stream belongs to the class of its last
+// picture; an I picture of another size moves it (its old slot is forgotten once the new picture's launch is queued),
+// a picture of another size with inter macroblocks is that stream's H263MI_ERR_PICTURE_FORMAT_INVALID (the reference
+// indexes the new planes with the old strides there, gather.rs:150,183).
+// =========================================================================================
+struct h263mi_mixed {
+    uint32_t n = 0;
+    h263mi_backend_cfg cfg{};
+    struct SizeClass {
+        uint32_t w = 0, h = 0;
+        h263mi_batch *b = nullptr;
+        bool submitted = false;                 // took part in the current call
+    };
+    std::vector<SizeClass> classes;
+    std::vector<int> cls;                       // per stream: index into `classes`, -1 = no picture yet
+    std::vector<bits::ParserContext> parser_ctx;
+    std::vector<bits::ParsedPicture> parsed;
+    std::unique_ptr<WorkerPool> pool;
+    ~h263mi_mixed()
+    {
+        for (SizeClass &c : classes) delete c.b;
+    }
+    WorkerPool &workers(unsigned want)
+    {
+        if (!pool || pool->size() < want) pool.reset(new WorkerPool(want - 1));
+        return *pool;
+    }
+    // the class of size (w, h); created on first use: nothing is allocated for sizes no stream has
+    int class_of(uint32_t w, uint32_t h, int *out)
+    {
+        for (size_t k = 0; k < classes.size(); k++)
+            if (classes[k].w == w && classes[k].h == h) { *out = (int)k; return H263MI_OK; }
+        h263mi_batch *b = nullptr;
+        RC_TRY(batch_create(n, w, h, &cfg, &b));
+        // no stream of a new class has a picture: every slot starts inactive and without one
+        SizeClass c;
+        c.w = w; c.h = h; c.b = b;
+        classes.push_back(c);
+        *out = (int)classes.size() - 1;
+        return H263MI_OK;
+    }
+};
+
+extern "C" {
+
+int h263mi_mixed_create(uint32_t n_streams, const h263mi_backend_cfg *cfg, h263mi_mixed **out)
+{
+    if (!out || !n_streams) return H263MI_ERR_INVALID_ARGUMENT;
+    const int dev = cfg ? cfg->device_id : 0;
+    RC_TRY(check_device(dev));
+    h263mi_mixed *m = new (std::nothrow) h263mi_mixed();
+    if (!m) return H263MI_ERR_OUT_OF_MEMORY;
+    m->n = n_streams;
+    if (cfg) m->cfg = *cfg;
+    m->cfg.device_id = dev;
+    m->cfg.flags &= ~H263MI_CFG_OVERLAP_POST;     // (one HIP stream carries the classes' launches back to back)
+    m->cls.assign(n_streams, -1);
+    m->parser_ctx.assign(n_streams, bits::ParserContext());
+    m->parsed.resize(n_streams);
+    *out = m;
+    return H263MI_OK;
+}
+
+void h263mi_mixed_destroy(h263mi_mixed *m) { delete m; }
+
+int h263mi_mixed_stream_size(const h263mi_mixed *m, uint32_t stream, uint16_t *width, uint16_t *height)
+{
+    if (!m || stream >= m->n) return H263MI_ERR_INVALID_ARGUMENT;
+    const int c = m->cls[stream];
+    const bool has = c >= 0 && m->classes[c].b->ss[stream].cur >= 0;
+    if (width) *width = has ? (uint16_t)m->classes[c].w : 0;
+    if (height) *height = has ? (uint16_t)m->classes[c].h : 0;
+    return has ? H263MI_OK : H263MI_ERR_NO_PICTURE;
+}
+
+uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m) { return m ? (uint32_t)m->classes.size() : 0; }
+
+int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options, const uint8_t *const *data, const size_t *len,
+                                      size_t *consumed, uint32_t n_threads, int *stream_rc, uint8_t strength,
+                                      uint8_t *const *d_rgba, const size_t *rgba_capacity, h263mi_picture_desc *descs)
+{
+    if (!m || !data || !len || !stream_rc || strength > 12 || (d_rgba && !rgba_capacity)) return H263MI_ERR_INVALID_ARGUMENT;
+    const uint32_t n = m->n;
+    for (uint32_t i = 0; i < n; i++)
+        if (!data[i] && len[i]) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(m->cfg.device_id);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    // ---- the serial half of decode_next_picture (state.rs:143-427) per stream, on the host threads
+    std::vector<int> rcs(n, H263MI_OK);
+    std::atomic<uint32_t> next{0};
+    auto work = [&](unsigned) {
+        for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            if (!data[i]) continue;
+            bits::ParsedPicture &pic = m->parsed[i];
+            pic.want_dense = false;
+            pic.mbs_ext = nullptr;               // (the class -- and with it the staging slot -- is known after the header)
+            pic.mbs_ext_cap = 0;
+            rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &m->parser_ctx[i], pic);
+        }
+    };
+    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
+    if (n_thr == 1) work(0);
+    else m->workers(n_thr).run(n_thr, work);
+
+    // ---- which class each picture goes to; what must be refused before anything is queued
+    std::vector<int> target(n, -1);
+    for (uint32_t i = 0; i < n; i++) {
+        if (consumed) consumed[i] = 0;
+        stream_rc[i] = rcs[i];
+        if (!data[i] || rcs[i] != H263MI_OK) continue;
+        const bits::ParsedPicture &pic = m->parsed[i];
+        const uint32_t w = pic.desc.width, h = pic.desc.height;
+        int rc = H263MI_OK;
+        if (!w || !h || !layout_fits(w, h)) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;
+        const size_t per = (size_t)((w + 15) / 16) * ((h + 15) / 16);
+        bool any_inter = pic.n_records() < per;                     // missing macroblocks are padded as Inter (state.rs:421-427)
+        const h263mi_mb_record *r = pic.records();
+        for (size_t k = 0, e = pic.n_records(); k < e && !any_inter; k++) any_inter = mb_is_inter(r[k].mb_type);
+        const int c_old = m->cls[i];
+        const bool same = c_old >= 0 && m->classes[c_old].w == w && m->classes[c_old].h == h;
+        const bool has_ref = c_old >= 0 && m->classes[c_old].b->ss[i].has_ref && m->classes[c_old].b->ss[i].cur >= 0;
+        if (rc == H263MI_OK && any_inter && !has_ref) rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS;          // gather.rs:149
+        if (rc == H263MI_OK && any_inter && !same) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;           // (see the head of this section)
+        if (rc == H263MI_OK && d_rgba && d_rgba[i] && rgba_capacity[i] < (size_t)w * h * 4) rc = H263MI_ERR_INVALID_ARGUMENT;
+        if (rc == H263MI_OK) rc = m->class_of(w, h, &target[i]);
+        if (rc != H263MI_OK) target[i] = -1;
+        stream_rc[i] = rc;
+    }
+    for (h263mi_mixed::SizeClass &c : m->classes) c.submitted = false;
+
+    // ---- one launch per class that has pictures
+    int call_rc = H263MI_OK;
+    std::vector<const h263mi_mb_record *> mbs(n);
+    std::vector<const uint32_t *> first(n), events(n);
+    std::vector<uint32_t> n_mbs(n), n_blocks(n), n_events(n);
+    std::vector<uint8_t> types(n), was_active(n);
+    std::vector<uint8_t *> out_ptrs(n);
+    static const uint32_t kNoEvents[1] = {0};
+    for (size_t k = 0; k < m->classes.size() && call_rc == H263MI_OK; k++) {
+        h263mi_batch *b = m->classes[k].b;
+        uint32_t members = 0;
+        bool any_out = false;
+        for (uint32_t i = 0; i < n; i++) {
+            const bool in = target[i] == (int)k;
+            was_active[i] = b->ss[i].active;
+            b->ss[i].active = in;
+            mbs[i] = nullptr; first[i] = kNoEvents; events[i] = nullptr;
+            n_mbs[i] = n_blocks[i] = n_events[i] = 0;
+            types[i] = H263MI_PICTURE_P;
+            out_ptrs[i] = nullptr;
+            if (!in) continue;
+            const bits::ParsedPicture &pic = m->parsed[i];
+            members++;
+            mbs[i] = pic.records();
+            n_mbs[i] = (uint32_t)pic.n_records();
+            first[i] = pic.block_first_event.data();
+            events[i] = pic.events.data();
+            n_blocks[i] = (uint32_t)pic.n_coded_blocks;
+            n_events[i] = (uint32_t)pic.events.size();
+            types[i] = pic.desc.picture_type;
+            if (d_rgba && d_rgba[i]) { out_ptrs[i] = d_rgba[i]; any_out = true; }
+            // a stream that arrives from another class starts afresh here (it brings an I picture)
+            if (m->cls[i] != (int)k) b->ss[i] = h263mi_batch::StreamState();
+            b->ss[i].active = true;
+        }
+        int rc = H263MI_OK;
+        if (members) {
+            const bool deferred = b->pipeline_post && any_out;
+            rc = batch_submit_host(b, H263MI_PICTURE_P, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
+                                   n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred);
+            if (rc == H263MI_OK) {
+                m->classes[k].submitted = true;
+                // the pictures are decoded: the streams move to this class, their parser state moves on (state.rs:464-483)
+                for (uint32_t i = 0; i < n; i++) {
+                    if (target[i] != (int)k) continue;
+                    const int c_old = m->cls[i];
+                    if (c_old >= 0 && c_old != (int)k) {
+                        // the slot the stream leaves: forgotten now, not earlier (its last picture lived there)
+                        h263mi_batch *ob = m->classes[c_old].b;
+                        const bool a = ob->ss[i].active;
+                        ob->ss[i] = h263mi_batch::StreamState();
+                        ob->ss[i].active = a;
+                        // (a rendering of the old picture that is still pending there is delivered all the same: it names the
+                        // frame set, and the frames themselves are not touched)
+                    }
+                    m->cls[i] = (int)k;
+                    m->parser_ctx[i] = m->parsed[i].next;
+                    if (consumed) consumed[i] = m->parsed[i].bits_consumed / 8;
+                    if (descs) descs[i] = m->parsed[i].desc;
+                }
+                int render_rc = H263MI_OK;
+                if (deferred) render_rc = b->note_pending(strength, nullptr, nullptr, out_ptrs.data());
+                else if (any_out) render_rc = b->render(strength, nullptr, nullptr, /*only_active=*/true, out_ptrs.data());
+                if (render_rc != H263MI_OK) call_rc = render_rc;
+            } else {
+                // the class's launch did not happen: its members keep their state and get the error
+                for (uint32_t i = 0; i < n; i++)
+                    if (target[i] == (int)k) stream_rc[i] = rc;
+            }
+        }
+        for (uint32_t i = 0; i < n; i++) b->ss[i].active = was_active[i] != 0;
+    }
+    // a class that is waiting to render its previous pictures and had nothing to decode in this call renders them now
+    // (on a pipelined class the rendering rides in the NEXT launch of that class: without one it would wait for the sync)
+    for (h263mi_mixed::SizeClass &c : m->classes)
+        if (!c.submitted && c.b->pending.valid) {
+            const int rc = c.b->flush_pending();
+            if (rc != H263MI_OK && call_rc == H263MI_OK) call_rc = rc;
+        }
+    return call_rc;
+}
+
+int h263mi_mixed_sync(h263mi_mixed *m, int *stream_rc)
+{
+    if (!m) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(m->cfg.device_id);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    if (stream_rc)
+        for (uint32_t i = 0; i < m->n; i++) stream_rc[i] = H263MI_OK;
+    int first_error = H263MI_OK;
+    std::vector<int> rcs(m->n);
+    for (size_t k = 0; k < m->classes.size(); k++) {
+        const int rc = m->classes[k].b->sync(rcs.data());
+        if (rc != H263MI_OK && first_error == H263MI_OK) first_error = rc;
+        for (uint32_t i = 0; i < m->n; i++)
+            if (stream_rc && m->cls[i] == (int)k && rcs[i] != H263MI_OK) stream_rc[i] = rcs[i];
+    }
+    return first_error;
+}
+
+int h263mi_mixed_copy_yuv(h263mi_mixed *m, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr)
+{
+    if (!m || stream >= m->n) return H263MI_ERR_INVALID_ARGUMENT;
+    if (m->cls[stream] < 0) return H263MI_ERR_NO_PICTURE;
+    DeviceGuard g(m->cfg.device_id);
+    return m->classes[m->cls[stream]].b->copy_yuv(stream, y, cb, cr);
+}
+
+int h263mi_mixed_reset_stream(h263mi_mixed *m, uint32_t stream)
+{
+    if (!m || stream >= m->n) return H263MI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(m->cfg.device_id);
+    if (!g.ok) return H263MI_ERR_NO_DEVICE;
+    int rc = H263MI_OK;
+    if (m->cls[stream] >= 0) rc = m->classes[m->cls[stream]].b->forget_stream(stream);
+    m->cls[stream] = -1;
+    m->parser_ctx[stream] = bits::ParserContext();
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------

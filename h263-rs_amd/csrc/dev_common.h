@@ -154,6 +154,8 @@ struct PostArgs {
     uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x) (set by the launcher)
     uint32_t wrap;               // 1: tile column 0 does not exist, its 4 picture columns ride in the last tile (post_kernel.inl)
     uint32_t pad;
+    uint8_t *const *rgba_ptrs;   // with stream_state only (or nullptr): picture p's RGBA goes to rgba_ptrs[p] instead of
+                                 // rgba + p * w*h*4 -- streams whose outputs are separate buffers (a batch of mixed sizes)
 };
 
 // ---------------------------------------------------------------------------

@@ -77,6 +77,8 @@ EXPORTS = [
     "h263mi_synth_picture_host", "h263mi_synth_batch_device",
     "h263mi_render_rgba_pinned", "h263mi_host_alloc", "h263mi_host_free", "h263mi_host_register", "h263mi_host_unregister",
     "h263mi_debug_fail_nth_hip_call",
+    "h263mi_mixed_create", "h263mi_mixed_destroy", "h263mi_mixed_decode_next_pictures", "h263mi_mixed_sync",
+    "h263mi_mixed_stream_size", "h263mi_mixed_size_classes", "h263mi_mixed_copy_yuv", "h263mi_mixed_reset_stream",
 ]
 
 
@@ -163,6 +165,16 @@ def lib():
         L.h263mi_host_register.argtypes = [vp, sz]
         L.h263mi_host_unregister.argtypes = [vp]
         L.h263mi_debug_fail_nth_hip_call.argtypes = [i32]
+        L.h263mi_mixed_create.argtypes = [u32, C.POINTER(BackendCfg), C.POINTER(vp)]
+        L.h263mi_mixed_destroy.argtypes = [vp]
+        L.h263mi_mixed_destroy.restype = None
+        L.h263mi_mixed_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp]
+        L.h263mi_mixed_sync.argtypes = [vp, vp]
+        L.h263mi_mixed_stream_size.argtypes = [vp, u32, C.POINTER(u16), C.POINTER(u16)]
+        L.h263mi_mixed_size_classes.argtypes = [vp]
+        L.h263mi_mixed_size_classes.restype = u32
+        L.h263mi_mixed_copy_yuv.argtypes = [vp, u32, vp, vp, vp]
+        L.h263mi_mixed_reset_stream.argtypes = [vp, u32]
         L.h263mi_batch_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32]
         L.h263mi_batch_decode_next_pictures_ex.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp]
         L.h263mi_batch_sync_streams.argtypes = [vp, vp]
@@ -586,6 +598,73 @@ class Batch:
 
 
 PROBE_COPY, PROBE_READ, PROBE_WRITE = 0, 1, 2
+
+
+class MixedBatch:
+    """h263mi_mixed: n streams of different (and changing) picture sizes, one launch per size class and call"""
+
+    def __init__(self, n_streams, device_id=0, stream=None, pipeline_post=False):
+        cfg = BackendCfg(device_id, 2 if pipeline_post else 0, stream)
+        h = C.c_void_p()
+        _check(lib().h263mi_mixed_create(n_streams, C.byref(cfg), C.byref(h)), "mixed_create")
+        self._h, self.n = h, n_streams
+
+    def close(self):
+        if self._h:
+            lib().h263mi_mixed_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, strength=0, rgba=None):
+        """data_list: bytes or None per stream; rgba: DeviceBuffer or None per stream (or None: no rendering).
+        Returns (bytes consumed, error codes, picture headers) per stream."""
+        assert len(data_list) == self.n
+        empty = np.zeros(1, np.uint8)
+        keep = [(np.frombuffer(bytes(d), dtype=np.uint8) if len(d) else empty) if d is not None else None for d in data_list]
+        pd = (C.c_void_p * self.n)(*[k.ctypes.data if k is not None else None for k in keep])
+        ln = (C.c_size_t * self.n)(*[(len(d) if d is not None else 0) for d in data_list])
+        used = (C.c_size_t * self.n)()
+        rcs = (C.c_int * self.n)()
+        descs = (PictureDesc * self.n)()
+        ptrs = caps = None
+        if rgba is not None:
+            ptrs = (C.c_void_p * self.n)(*[(r.ptr.value if hasattr(r.ptr, "value") else r.ptr) if r is not None else None for r in rgba])
+            caps = (C.c_size_t * self.n)(*[r.nbytes if r is not None else 0 for r in rgba])
+        _check(lib().h263mi_mixed_decode_next_pictures(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength, ptrs, caps,
+                                                       descs), "mixed_decode_next_pictures")
+        return list(used), list(rcs), list(descs)
+
+    def sync(self):
+        rcs = (C.c_int * self.n)()
+        rc = lib().h263mi_mixed_sync(self._h, rcs)
+        if rc != OK and not any(rcs):
+            raise H263Error(rc, "mixed_sync")
+        return list(rcs)
+
+    def stream_size(self, stream):
+        w, h = C.c_uint16(0), C.c_uint16(0)
+        lib().h263mi_mixed_stream_size(self._h, stream, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def size_classes(self):
+        return lib().h263mi_mixed_size_classes(self._h)
+
+    def copy_yuv(self, stream):
+        w, h = self.stream_size(stream)
+        if not w:
+            raise H263Error(ERR_NO_PICTURE, "mixed_copy_yuv")
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        y, cb, cr = np.empty(w * h, np.uint8), np.empty(cw * ch, np.uint8), np.empty(cw * ch, np.uint8)
+        _check(lib().h263mi_mixed_copy_yuv(self._h, stream, _p(y), _p(cb), _p(cr)), "mixed_copy_yuv")
+        return y, cb, cr
+
+    def reset_stream(self, stream):
+        _check(lib().h263mi_mixed_reset_stream(self._h, stream), "mixed_reset_stream")
 
 
 def probe_bandwidth(mode, nbytes=1 << 30, reps=10, device_id=0, stream=None, with_shape=False):

@@ -426,6 +426,50 @@ typedef struct h263mi_kernel_times {
 } h263mi_kernel_times;
 int h263mi_batch_timing_begin(h263mi_batch *b);
 int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out);
+
+/* ======================================================================= */
+/* Streams of DIFFERENT picture sizes behind one call  (ABI 4)              */
+/* ======================================================================= */
+/*
+ * The reference resolves the picture format per H263State and per picture (state.rs:157-176): a server holds QCIF, CIF and
+ * 1080p streams side by side and a stream may change its size at an I picture.  h263mi_batch takes one size; h263mi_mixed
+ * keeps one such batch per size CLASS (created when the first stream of that size shows up) and decodes, per call, every
+ * class that has pictures with ONE launch, back to back on cfg's HIP stream: QCIF + CIF + 1080p streams cost three
+ * launches per call, not one per stream.  cfg->flags: H263MI_CFG_PIPELINE_POST makes every class frame-pipelined (the
+ * RGBA of a picture is written by the launch that decodes the class's NEXT pictures, or -- when the class has none in
+ * the next call -- at the end of that call; h263mi_mixed_sync delivers everything).
+ *
+ * h263mi_mixed_decode_next_pictures = N x H263State::decode_next_picture (state.rs:138-141), every stream its own state:
+ *   data[s] / len[s]   one coded picture of stream s, or NULL: no picture for it in this call;
+ *   stream_rc[s]       H263MI_OK or the stream's own error: a parse error, H263MI_ERR_UNCODED_IFRAME_BLOCKS (inter
+ *                      macroblocks without a reference picture), H263MI_ERR_PICTURE_FORMAT_INVALID (a picture of another
+ *                      size than the stream's last one that is not all intra: the reference indexes the new planes with the old
+ *                      strides there, gather.rs:150,183), H263MI_ERR_INVALID_ARGUMENT (rgba_capacity[s] too small), a
+ *                      back-end error of its class's launch.  A stream that fails keeps its state, parser state included
+ *                      (state.rs:142); the others advance.  A picture of another size that is all intra MOVES the stream
+ *                      to that size (its old picture is given up when the new one's launch is queued, not before);
+ *   d_rgba[s]          (d_rgba may be NULL: no rendering) DEVICE buffer of rgba_capacity[s] >= w*h*4 bytes of the picture
+ *                      being decoded, or NULL for that stream: deblock(strength) + BT.601 of the picture, tightly packed;
+ *   descs[s]           (may be NULL) receives the header fields of the picture stream s decoded, its size included.
+ * Returns H263MI_OK when the call itself went through (look at stream_rc), else a back-end error.
+ */
+typedef struct h263mi_mixed h263mi_mixed;
+int h263mi_mixed_create(uint32_t n_streams, const h263mi_backend_cfg *cfg, h263mi_mixed **out);
+void h263mi_mixed_destroy(h263mi_mixed *m);
+int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options, const uint8_t *const *data,
+                                      const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
+                                      uint8_t strength, uint8_t *const *d_rgba, const size_t *rgba_capacity,
+                                      h263mi_picture_desc *descs);
+/* waits for everything queued; stream_rc (may be NULL): the device's verdict per stream, as h263mi_batch_sync_streams */
+int h263mi_mixed_sync(h263mi_mixed *m, int *stream_rc);
+/* size of stream `stream`'s last picture (H263MI_ERR_NO_PICTURE and 0 x 0 when it has none) */
+int h263mi_mixed_stream_size(const h263mi_mixed *m, uint32_t stream, uint16_t *width, uint16_t *height);
+/* number of size classes (fixed-geometry batches) created so far */
+uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m);
+/* DecodedPicture::as_yuv of stream `stream`'s last picture: tightly packed planes to HOST memory */
+int h263mi_mixed_copy_yuv(h263mi_mixed *m, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr);
+/* H263State::new for one stream: it forgets its pictures and its size */
+int h263mi_mixed_reset_stream(h263mi_mixed *m, uint32_t stream);
 /* Create the events for `n_launches` timed kernel launches ahead of time, so that none is created inside a
  * timed region. */
 int h263mi_batch_timing_reserve(h263mi_batch *b, uint32_t n_launches);

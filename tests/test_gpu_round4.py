@@ -348,3 +348,84 @@ def test_event_bounds_from_device_memory_are_checked_against_n_events():
     rcs = b.sync_streams()
     assert rcs[0] == h263mi.ERR_INVALID_ARGUMENT and rcs[1] == 0
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# streams of different sizes behind one call (h263mi_mixed_*): QCIF + CIF + 1080p + an odd size in one set, every stream
+# against its own oracle chain; a stream changes its size at an I picture (state.rs:157-176) and keeps decoding; a size
+# change under inter prediction is that stream's PICTURE_FORMAT_INVALID and leaves it where it was
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_mixed_sizes_in_one_set(pipeline):
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    q, strength = 6, 5
+    sizes = [(176, 144), (352, 288), (1920, 1080), (176, 144), (100, 60), (352, 288), (176, 144), (1920, 1080)]
+    n = len(sizes)
+    m = h263mi.MixedBatch(n, pipeline_post=pipeline)
+    refs = [None] * n
+    cur = list(sizes)
+    calls = 7
+    rgba = [[h263mi.DeviceBuffer(1920 * 1080 * 4) for _ in range(n)] for _ in range(calls)]
+    rendered = []                                                # (call, stream, w, h, expected RGBA)
+
+    def picture(s, f, intra, size):
+        w, h = size
+        if intra:
+            mbs, co = recgen.intra_picture(w, h, seed=1000 * f + s, max_level=60)
+            mbs = make_codable(mbs, q, s, 0)
+        else:
+            mbs, co = recgen.inter_picture(w, h, seed=1000 * f + s, mv_range=32, p_4v=0.2, p_intra=0.05, p_coded=0.4, quant=q, max_level=60)
+            mbs = make_codable(mbs, q, s + f, 1)
+        return enc.encode_picture(w, h, 0 if intra else 1, q, mbs, co, temporal_reference=f), mbs, co
+
+    def step(f, plan, expect_rc):
+        """plan[s]: ('I' | 'P', size) or None; default ('P', the stream's current size)"""
+        datas = []
+        for s in range(n):
+            item = plan.get(s, ("P", cur[s]))
+            if item is None:
+                datas.append(None)
+                continue
+            kind, size = item
+            data, mbs, co = picture(s, f, kind == "I", size)
+            datas.append(data)
+            if expect_rc.get(s, 0) == 0:
+                rc, refs[s] = orc.decode_picture(size[0], size[1], mbs, co, None if kind == "I" else refs[s])
+                assert rc == 0
+                cur[s] = size
+                rendered.append((f, s, size[0], size[1], _rgba_want(refs[s], strength, size[0])))
+        used, rcs, descs = m.decode_next_pictures(datas, n_threads=3, strength=strength, rgba=rgba[f])
+        for s in range(n):
+            assert rcs[s] == expect_rc.get(s, 0), "call %d stream %d: rc %d" % (f, s, rcs[s])
+            if datas[s] is not None and rcs[s] == 0:
+                assert used[s] > 0 and (descs[s].width, descs[s].height) == cur[s]
+        assert not any(m.sync())
+        for s in range(n):
+            if refs[s] is None:
+                assert m.stream_size(s) == (0, 0)
+            else:
+                assert m.stream_size(s) == cur[s]
+                assert_planes_equal(m.copy_yuv(s), refs[s], "after call %d, stream %d" % (f, s))
+
+    step(0, {s: ("I", sizes[s]) for s in range(n)}, {})
+    assert m.size_classes() == 4
+    step(1, {}, {})
+    # stream 3 (QCIF) changes to CIF at an I picture; stream 6 (QCIF) tries to change under inter prediction: refused;
+    # stream 4 sits the call out
+    step(2, {3: ("I", (352, 288)), 6: ("P", (352, 288)), 4: None}, {6: h263mi.ERR_PICTURE_FORMAT_INVALID})
+    assert m.size_classes() == 4
+    step(3, {}, {})                                              # 3 predicts at CIF, 6 still at QCIF from its picture of call 1
+    # a size no stream has had yet: a new class appears in mid-stream; the 1080p stream 7 shrinks to it
+    step(4, {7: ("I", (640, 360)), 1: None}, {})
+    assert m.size_classes() == 5
+    step(5, {}, {})
+    m.reset_stream(0)
+    refs[0] = None
+    step(6, {0: ("P", (176, 144))}, {0: h263mi.ERR_UNCODED_IFRAME_BLOCKS})
+    for f, s, w, h, want in rendered:
+        got = rgba[f][s].download(w * h * 4)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "RGBA of call %d stream %d (%dx%d): %d bytes differ" % (f, s, w, h, bad.size)
+    m.close()

@@ -40,7 +40,10 @@ class NativeOracle:
         self.srcs = srcs
         self.path = os.path.join(out_dir, "libh263oracle_native_%s.so" % _cpu_key())
         if not os.path.exists(self.path) or any(os.path.getmtime(self.path) < os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["gcc"] + FLAGS + ["-shared", "-o", self.path] + srcs)
+            # (built under a private name and moved into place: several test workers may get here at the same time)
+            tmp = "%s.%d.tmp" % (self.path, os.getpid())
+            subprocess.check_call(["gcc"] + FLAGS + ["-shared", "-o", tmp] + srcs)
+            os.replace(tmp, self.path)
         self.flags = "gcc " + " ".join(FLAGS)
         L = C.CDLL(self.path)
         orc.bind(L)

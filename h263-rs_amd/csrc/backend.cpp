@@ -4,6 +4,7 @@
 // kernels.hip -- there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
 #include <sched.h>
 
 #include <new>
@@ -85,17 +86,23 @@ struct DeviceGuard {
 // h263mi_batch_decode_next_pictures used to start and join two sets of threads per frame index.  run(k, fn) executes
 // fn(0) .. fn(k - 1), fn(0) on the calling thread, and returns when all are done; calls do not nest or overlap (a batch
 // is driven from one thread at a time).
+// A server calls the batch entries back to back, a millisecond apart: waking 15 parked threads through a condition
+// variable cost 50-100 us of every call (twice: parser tasks, then packing).  A worker therefore SPINS on the generation
+// counter for a short while after it has finished a task (kSpinUs) and only then parks; the caller spins likewise while
+// it waits for the last worker.  An idle batch costs nothing: everybody is parked.
 class WorkerPool {
 public:
     explicit WorkerPool(unsigned workers)
     {
         for (unsigned t = 0; t < workers; t++) threads_.emplace_back([this, t] { loop(t + 1); });
+        keep_off_sibling_hyperthreads();
     }
     ~WorkerPool()
     {
         {
             std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
+            stop_.store(true, std::memory_order_release);
+            generation_.store(((generation_.load(std::memory_order_relaxed) >> 32) + 1) << 32, std::memory_order_release);
         }
         wake_.notify_all();
         for (std::thread &t : threads_) t.join();
@@ -105,45 +112,117 @@ public:
     {
         if (k > size()) k = size();
         if (k <= 1) { fn(0); return; }
+        fn_ = &fn;
+        pending_.store(k - 1, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn;
-            active_ = k;
-            pending_ = k - 1;
-            generation_++;
+            // generation and the number of threads it is for travel in ONE word: a worker that is late for a generation it
+            // has no part in must not pair that generation with the next one's thread count
+            std::lock_guard<std::mutex> l(m_);                            // (orders the bump against a worker about to park)
+            const uint64_t gen = (generation_.load(std::memory_order_relaxed) >> 32) + 1;
+            generation_.store((gen << 32) | k, std::memory_order_release);
         }
-        wake_.notify_all();
+        if (parked_.load(std::memory_order_acquire)) wake_.notify_all();
         fn(0);
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
+        for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
+            if (spins < 20000) cpu_relax();
+            else std::this_thread::yield();
+        }
         fn_ = nullptr;
     }
 
 private:
+    // The parser is a chain of dependent table look-ups: two of its threads on the two hyperthreads of one core run at
+    // 60-70 % each.  On a host with many more cores than worker threads (the GPU boxes: 16 CPUs of quota on 128 cores / 256
+    // hyperthreads) the workers are therefore confined to ONE hyperthread per physical core -- the lowest-numbered of each
+    // sibling set, within the affinity mask the process already has -- and the scheduler spreads them over distinct cores.
+    // Every process makes the same choice, so eight ranks with 16 workers each still find 128 distinct cores.  Only the
+    // pool's own threads are touched (never the caller's); H263MI_PIN_THREADS=0 leaves them alone.
+    void keep_off_sibling_hyperthreads()
+    {
+        const char *env = getenv("H263MI_PIN_THREADS");
+        if (env && env[0] == '0') return;
+        cpu_set_t have, want;
+        if (sched_getaffinity(0, sizeof have, &have) != 0) return;
+        CPU_ZERO(&want);
+        for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
+            if (!CPU_ISSET(cpu, &have)) continue;
+            char path[128];
+            snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+            FILE *f = fopen(path, "r");
+            int first = cpu;
+            if (f) {
+                if (fscanf(f, "%d", &first) != 1) first = cpu;      // "3,131" or "3-4": the list starts with its lowest member
+                fclose(f);
+            }
+            if (first == cpu || !CPU_ISSET(first, &have)) CPU_SET(cpu, &want);
+        }
+        // only when that still leaves room to spread: at least twice as many cores as workers
+        if ((unsigned)CPU_COUNT(&want) < 2 * (unsigned)threads_.size() + 2 || CPU_COUNT(&want) == CPU_COUNT(&have)) return;
+        for (std::thread &t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want);
+    }
+    static constexpr long kSpinUs = 300;
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     void loop(unsigned id)
     {
-        unsigned seen = 0;
+        uint64_t seen = 0;                               // generation << 32 | threads of that generation
         for (;;) {
-            const std::function<void(unsigned)> *fn = nullptr;
-            {
-                std::unique_lock<std::mutex> l(m_);
-                wake_.wait(l, [&] { return stop_ || generation_ != seen; });
-                if (stop_) return;
-                seen = generation_;
-                if (id < active_) fn = fn_;
+            // spin for the next task, then park
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned polls = 0;
+            uint64_t now;
+            while ((now = generation_.load(std::memory_order_acquire)) == seen) {
+                cpu_relax();
+                if ((++polls & 255u) == 0 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinUs) {
+                    std::unique_lock<std::mutex> l(m_);
+                    parked_.fetch_add(1, std::memory_order_release);
+                    wake_.wait(l, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                    parked_.fetch_sub(1, std::memory_order_release);
+                }
             }
-            if (!fn) continue;
-            (*fn)(id);
-            std::lock_guard<std::mutex> l(m_);
-            if (--pending_ == 0) done_.notify_one();
+            if (stop_.load(std::memory_order_acquire)) return;
+            seen = now;
+            if (id >= (unsigned)(now & 0xffffffffu)) continue;           // no part in this generation
+            (*fn_)(id);                                  // (fn_ cannot change before this thread has reported back)
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> threads_;
     std::mutex m_;
-    std::condition_variable wake_, done_;
+    std::condition_variable wake_;
     const std::function<void(unsigned)> *fn_ = nullptr;
-    unsigned active_ = 0, pending_ = 0, generation_ = 0;
-    bool stop_ = false;
+    std::atomic<unsigned> pending_{0}, parked_{0};
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<bool> stop_{false};
+};
+
+// Streams dealt to host threads with AFFINITY: thread t of T first takes the streams t, t + T, t + 2T, ... -- the same ones
+// in every call, so that a stream's parse buffers and its slot of the staging memory (261 KB of records per 1080p picture)
+// stay in that core's caches instead of migrating between cores from call to call -- and then helps out with whatever
+// the other threads have not started yet (a stream is claimed with one atomic exchange).
+struct StreamDeal {
+    std::unique_ptr<std::atomic<uint8_t>[]> taken;
+    uint32_t n = 0;
+    explicit StreamDeal(uint32_t n_streams) : taken(new std::atomic<uint8_t>[n_streams]), n(n_streams)
+    {
+        for (uint32_t i = 0; i < n; i++) taken[i].store(0, std::memory_order_relaxed);
+    }
+    template <class F> void run(unsigned t, unsigned n_threads, F &&task)
+    {
+        for (uint32_t i = t; i < n; i += n_threads)
+            if (!taken[i].exchange(1, std::memory_order_relaxed)) task(i);
+        for (uint32_t k = 0; k < n; k++) {               // leftovers, starting behind the own ones
+            const uint32_t i = (k + t) % n;
+            if (!taken[i].load(std::memory_order_relaxed) && !taken[i].exchange(1, std::memory_order_relaxed)) task(i);
+        }
+    }
 };
 
 uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
@@ -245,6 +324,7 @@ struct h263mi_batch {
     size_t frame_skew = 0;
     unsigned host_calls = 0;
     bool trace_host = getenv("H263MI_TRACE_E2E") != nullptr;
+    bool trace_each = trace_host && getenv("H263MI_TRACE_E2E")[0] == '2';
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -1017,8 +1097,8 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     uint32_t *h_first = g2.h_events, *h_ev = sparse ? g2.h_events + blocks + 1 : nullptr;
     std::atomic<bool> offsets_ok{true}, records_ok{true};
     // packing is a host memcpy of every record byte: a few threads, or one core caps the rate below the PCIe link
-    auto pack = [&](uint32_t first, uint32_t last) {
-        for (uint32_t i = first; i < last; i++) {
+    auto pack = [&](uint32_t first, uint32_t last, uint32_t step) {
+        for (uint32_t i = first; i < last; i += step) {
             if (!b->ss[i].active) continue;      // sits the call out: its records are never read (STREAM_RECON_SKIP)
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
             for (uint32_t k = 0; k < n_mbs[i] && !from_parser; k++) {   // the same checks as h263mi_submit_picture
@@ -1061,11 +1141,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     const uint32_t n_thr = bytes < (4u << 20) ? 1u
                          : std::min<uint32_t>({pack_threads ? pack_threads : 8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
     if (n_thr <= 1) {
-        pack(0, b->n);
+        pack(0, b->n, 1);
     } else {
-        b->workers(n_thr).run(n_thr, [&](unsigned t) {
-            pack((uint32_t)((uint64_t)b->n * t / n_thr), (uint32_t)((uint64_t)b->n * (t + 1) / n_thr));
-        });
+        // (thread t packs the streams t, t + T, ...: the ones it has just parsed, see StreamDeal)
+        b->workers(n_thr).run(n_thr, [&](unsigned t) { pack(t, b->n, n_thr); });
     }
     if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
     const auto t_enq0 = std::chrono::steady_clock::now();
@@ -1106,6 +1185,11 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         b->host_ms[2] += std::chrono::duration<double, std::milli>(t_enq0 - t_pack0).count();
         b->host_ms[3] += std::chrono::duration<double, std::milli>(t_end - t_enq0).count();
         b->host_calls++;
+        if (b->trace_each)                       // H263MI_TRACE_E2E=2: one line per call
+            fprintf(stderr, "h263mi call %u: wait %.3f pack %.3f enqueue %.3f ms (%zu blocks, %zu events)\n", b->host_calls,
+                    std::chrono::duration<double, std::milli>(t_pack0 - t_wait0).count(),
+                    std::chrono::duration<double, std::milli>(t_enq0 - t_pack0).count(),
+                    std::chrono::duration<double, std::milli>(t_end - t_enq0).count(), blocks, n_ev);
     }
     return H263MI_OK;
 }
@@ -1180,10 +1264,11 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     const size_t per = (size_t)b->L.mbw * b->L.mbh;
     // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
     std::vector<int> rcs(n, H263MI_OK);
-    std::atomic<uint32_t> next{0};
-    auto work = [&](unsigned) {
-        for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            if (!data[i] || !b->ss[i].active) continue;          // no picture for this stream in this call
+    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
+    StreamDeal deal(n);
+    auto work = [&](unsigned t) {
+        deal.run(t, n_thr, [&](uint32_t i) {
+            if (!data[i] || !b->ss[i].active) return;            // no picture for this stream in this call
             bits::ParsedPicture &pic = b->parsed[i];
             pic.want_dense = false;                              // the coefficients travel as events
             pic.mbs_ext = g2.h_mbs + (size_t)i * per;
@@ -1200,13 +1285,16 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
                 if (rc == H263MI_OK && pic.n_records() < per) rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS;
             }
             rcs[i] = rc;
-        }
+        });
     };
-    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
     const auto t_parse0 = std::chrono::steady_clock::now();
     if (n_thr == 1) work(0);
     else b->workers(n_thr).run(n_thr, work);
-    if (b->trace_host) b->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
+    if (b->trace_host) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
+        b->host_ms[0] += ms;
+        if (b->trace_each) fprintf(stderr, "h263mi parse phase: %.3f ms on %u threads\n", ms, n_thr);
+    }
     std::vector<uint8_t> takes_part(n), types(n, H263MI_PICTURE_P);
     int first_error = H263MI_OK;
     uint32_t n_ok = 0;
@@ -1489,18 +1577,18 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
     // ---- the serial half of decode_next_picture (state.rs:143-427) per stream, on the host threads
     std::vector<int> rcs(n, H263MI_OK);
-    std::atomic<uint32_t> next{0};
-    auto work = [&](unsigned) {
-        for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            if (!data[i]) continue;
+    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
+    StreamDeal deal(n);
+    auto work = [&](unsigned t) {
+        deal.run(t, n_thr, [&](uint32_t i) {
+            if (!data[i]) return;
             bits::ParsedPicture &pic = m->parsed[i];
             pic.want_dense = false;
             pic.mbs_ext = nullptr;               // (the class -- and with it the staging slot -- is known after the header)
             pic.mbs_ext_cap = 0;
             rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &m->parser_ctx[i], pic);
-        }
+        });
     };
-    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
     if (n_thr == 1) work(0);
     else m->workers(n_thr).run(n_thr, work);
 

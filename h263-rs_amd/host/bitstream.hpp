@@ -203,6 +203,18 @@ struct ParserContext {
 int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserContext *prev, PictureHeader &out,
                           bool &is_picture);
 
+// A std::vector whose resize() does not zero-fill: the parser's word arrays are sized for the worst case of a picture up
+// front (200 KB for the block offsets of a 1080p picture) and every element that counts is written before it is read.
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef DefaultInitAlloc<U> other; };
+    DefaultInitAlloc() = default;
+    template <class U> DefaultInitAlloc(const DefaultInitAlloc<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint32_t, DefaultInitAlloc<uint32_t>> WordBuffer;
+
 // ---- whole picture -> records (state.rs:138-427) ------------------------------------------------------
 struct ParsedPicture {
     h263mi_picture_desc desc{};
@@ -217,7 +229,7 @@ struct ParsedPicture {
     size_t n_records() const { return mbs_ext_used ? n_mbs_ext : mbs.size(); }
     std::vector<int16_t> coeffs;           // 64 per coded block, raster order (only with want_dense)
     // the same coefficients as events, level << 16 | raster position, block k = [block_first_event[k], [k+1])
-    std::vector<uint32_t> block_first_event, events;
+    WordBuffer block_first_event, events;
     bool want_dense = true;                // set to false before parsing to skip the dense blocks
     // Test switch: read every field on its own, with its own end-of-data check -- the transcription of the reference's
     // parser that defines the behaviour -- instead of the windowed fast paths.  tests/test_parser_paths.py holds the two
@@ -225,7 +237,7 @@ struct ParsedPicture {
     bool field_by_field = false;
     size_t n_coded_blocks = 0;
     size_t bits_consumed = 0;
-    std::vector<uint32_t> scratch;         // parser-internal (the vectors of the macroblocks decoded so far)
+    WordBuffer scratch;                    // parser-internal (the vectors of the macroblocks decoded so far)
     ParserContext next;                    // the context once this picture has been decoded successfully
 };
 // Returns H263MI_OK or the error the reference's decode_next_picture would return before touching any

@@ -1,0 +1,36 @@
+"""Per-call wall time of the end-to-end path over one GOP (64 realistic 1080p streams, 16 parser threads): which calls are
+slow -- the key frame, the first P pictures behind it, all of them?  usage (GPU box): python tools/probes/e2e_per_call.py [threads]"""
+import os, sys, time
+import torch
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "h263-rs_amd")); sys.path.insert(0, os.path.join(R, "tests"))
+import bench, h263mi, recgen
+import sorenson_enc as enc
+from test_bitstream_e2e import make_codable
+W, H, n = bench.W, bench.H, 64
+threads = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+torch.cuda.set_device(0)
+stream = torch.cuda.current_stream().cuda_stream
+d_rgba = h263mi.DeviceBuffer(n * bench.RGBA_BYTES, 0)
+pics = []
+for f in range(8):
+    mbs, co = (recgen.realistic_intra_picture(W, H, 300) if f == 0 else recgen.realistic_inter_picture(W, H, 7000 + f))
+    pics.append(enc.encode_picture(W, H, 0 if f == 0 else 1, 10, make_codable(mbs, 10, f, 0 if f == 0 else 1), co, temporal_reference=f))
+batch = h263mi.Batch(n, W, H, 0, stream, pipeline_post=True)
+prepared = [batch.prepare_pictures([pics[f]] * n) for f in range(8)]
+order = [0] + [1 + k % 7 for k in range(30)]
+for rep in range(3):
+    times = []
+    t_gop = time.perf_counter()
+    for f in order:
+        t0 = time.perf_counter()
+        batch.decode_next_pictures_ex(None, n_threads=threads, prepared=prepared[f], strength=5, d_rgba=d_rgba.ptr)
+        times.append(time.perf_counter() - t0)
+    t_sync = time.perf_counter()
+    batch.sync()
+    t_end = time.perf_counter()
+    print("GOP %d: %.2f ms (%d pictures/s); I call %.3f ms; P calls: first %.3f, median %.3f, max %.3f ms; final sync %.3f ms" % (
+        rep, (t_end - t_gop) * 1e3, n * 31 / (t_end - t_gop), times[0] * 1e3, times[1] * 1e3, sorted(times[1:])[15] * 1e3,
+        max(times[1:]) * 1e3, (t_end - t_sync) * 1e3), flush=True)
+print("P calls of the last GOP (ms):", " ".join("%.2f" % (t * 1e3) for t in times[1:]))
+batch.close()

@@ -158,6 +158,7 @@ struct RoundState {
     uint64_t rows_any, cols_any;        // ballots of the row classes (recon_row_class)
     uint32_t rows_mask;                 // bit r: some block of the round has something in coefficient row r
     bool any_special;                   // some block of the round is Vert, Dc or Zero
+    bool dense;                         // every row of every block of the round reaches its last pair: eight Full blocks
 };
 
 template <bool FIRST, bool MC>
@@ -169,6 +170,18 @@ __device__ __forceinline__ void recon_round_rows(const ReconArgs &a, ReconWave &
     ISA_MARK2(MC, "mc_", "intra_", "round_begin");
     recon_phase_idct_load(a, s, f, ln, p, FIRST ? 0 : round, rs.ri, km);
     ISA_MARK2(MC, "mc_", "intra_", "idct_load_end");
+    // The dense round -- every block of a dense I picture's waves (BASELINE configs[1]) -- is recognised by ONE ballot: a
+    // non-zero LEVEL in columns 6..7 of every lane's coefficient row means eight active blocks (an empty slot holds zeros)
+    // that all have something beyond their first column in every row: eight Full blocks, eight columns, eight rows
+    // (rle.rs:138-149).  They take the instantiation without any of the general form's bookkeeping.
+    rs.dense = __ballot(rs.ri.w[3] != 0) == ~0ull;
+    if (rs.dense) {
+        wave_fence();                       // the column pass of the previous round has read tbuf
+        recon_phase_idct_rows<true>(s, rs.ri, ln, 8, ~0ull);
+        wave_fence();                       // the row pass results are in LDS
+        ISA_MARK2(MC, "mc_", "intra_", "idct_rows_end");
+        return;
+    }
     // which coefficient columns / rows the 8 blocks of this round use at all: the passes stop there
     const uint32_t wm = (__ballot(rs.ri.w[1] != 0) ? 2u : 0u) | (__ballot(rs.ri.w[2] != 0) ? 4u : 0u) |
                         (__ballot(rs.ri.w[3] != 0) ? 8u : 0u);
@@ -191,7 +204,8 @@ __device__ __forceinline__ void recon_round_cols(ReconWave &s, int lane, const R
 {
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    recon_phase_idct_cols(s, rs.ri, ln, rows_from_mask(rs.rows_mask), rs.rows_any, rs.cols_any, rs.any_special, /*strip_is_zero=*/!MC);
+    if (rs.dense) recon_phase_idct_cols<true>(s, rs.ri, ln, 8, ~0ull, ~0ull, false, /*strip_is_zero=*/!MC);
+    else recon_phase_idct_cols(s, rs.ri, ln, rows_from_mask(rs.rows_mask), rs.rows_any, rs.cols_any, rs.any_special, /*strip_is_zero=*/!MC);
     ISA_MARK2(MC, "mc_", "intra_", "idct_cols_end");
 }
 

@@ -846,15 +846,21 @@ H263_DEV RowClass recon_row_class(const RowIn &ri, int lane)
 // column directly (idct.rs:152-169) or uses the DC as it stands (idct.rs:119).  Here such a block runs the row
 // pass with 1.0 in the place of B[0][i]: T[r][i] = C[r][0] exactly, for every i, so that the column pass finds the
 // untouched first column in whichever column of T it reads.
+// DENSE (round 4): the round is known to be "all Full" -- eight blocks, every coefficient row of every one of them with a
+// non-zero LEVEL in its last pair (kernels.hip: recon_round_rows decides it with one ballot).  Nothing of what the general
+// form spends on being general is left: no activity mask, no class, no column count -- dequantise 4 pairs, 8 terms, store.
+// The arithmetic is the general form's with n_cols = 8 and no first-column-only block: bit for bit the same results.
+template <bool DENSE = false>
 H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols, uint64_t cols_any)
 {
-    if (!ri.active) return;
+    if (!DENSE && !ri.active) return;
+    if (DENSE) n_cols = 8;
     const int slot = lane >> 3, r = lane & 7;
     const uint32_t quant = desc_quant(ri.d1);
     // 2q and q - (q even) = (q - 1) | 1 in both halves of a dword
     const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = ((quant - 1u) | 1u) * 0x00010001u;
     const bool use_dc = desc_intra(ri.d1) && r == 0;
-    const bool first_column_only = ((uint32_t)(cols_any >> (8 * slot)) & 0xffu) == 0;
+    const bool first_column_only = !DENSE && ((uint32_t)(cols_any >> (8 * slot)) & 0xffu) == 0;
 
     float C[8];
 #pragma unroll
@@ -881,10 +887,12 @@ H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
 // Vert when no row holds anything beyond column 0, Dc (or Zero) when both (rle.rs:138-171).
 // strip_is_zero: no macroblock of the wave takes a prediction (an all-intra wave): the strip holds zeros wherever a
 // block of the wave is about to be written, so the residual is the pixel and the read + add of the strip are left out.
+template <bool DENSE = false>
 H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int n_rows, uint64_t rows_any, uint64_t cols_any,
                                     bool any_special, bool strip_is_zero = false)
 {
-    if (!ri.active) return;
+    if (!DENSE && !ri.active) return;
+    if (DENSE) { n_rows = 8; any_special = false; }
     const int slot = lane >> 3, i = lane & 7;
     const int t = desc_task(ri.d1);
     const uint32_t slot_rows = (uint32_t)(rows_any >> (8 * slot)) & 0xfeu, slot_cols = (uint32_t)(cols_any >> (8 * slot)) & 0xffu;

@@ -487,6 +487,9 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 // at the same time on the same XCD: the planes are fetched from HBM once per frame instead of twice, and waves
 // bound by arithmetic and address work (reconstruction) share every CU with waves bound by stores (RGBA).
 // ---------------------------------------------------------------------------------------
+#if defined(H263MI_EXP_WAVES_PER_EU)
+__attribute__((amdgpu_waves_per_eu(1, H263MI_EXP_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg)
 {
 #if defined(H263MI_LDS_PAD)

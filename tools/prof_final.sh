@@ -14,7 +14,9 @@ R=$PWD; OUT=$R/gpurun_out/final_$TAG; mkdir -p $OUT
 PROF_ARGS="--gops-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-parity-gate"
 cd /tmp && export TMPDIR=/tmp
 # ---- the box
-( [ -x $R/build/ceiling ] && timeout 200 $R/build/ceiling 1024 | grep "BEST\|hipMemcpy" ) > $OUT/box.txt 2>&1
+# (the probe is built here, on the box: build/ does not travel with the snapshot any more)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/probes/ceiling.hip -o /tmp/ceiling 2> /dev/null
+( [ -x /tmp/ceiling ] && timeout 200 /tmp/ceiling 1024 | grep "BEST\|hipMemcpy" ) > $OUT/box.txt 2>&1
 STAMP="box: $(grep 'BEST copy' $OUT/box.txt | awk '{print $3" GB/s copy ceiling"}'), $(hostname), $(date -u +%Y-%m-%dT%H:%MZ)"
 echo "$STAMP" >> $OUT/box.txt
 echo "== $STAMP"
@@ -24,6 +26,11 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_$C.log
 done
+# ... and the request counters behind them, by size (round 4: tools/fetch_calib.sh shows that EVERY read request of the L2s
+# is 128 bytes on gfx950, for k_frame's gathers and strip loads as for streaming reads -- FETCH_SIZE, which prices a request
+# at 64 bytes, times 2 is exact; TCC_EA0_RDREQ_DRAM_32B x 32 bytes agrees to 0.2 %)
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv -d $OUT/pmc_RDREQ -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_RDREQ.log
+timeout 600 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum --output-format csv -d $OUT/pmc_WRREQ -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_WRREQ.log
 cd $R
 python3 - "$OUT" "$TAG" "$STAMP" <<'PY'
 import csv, glob, json, os, sys, collections
@@ -31,7 +38,7 @@ sys.path.insert(0, os.getcwd())
 import bench
 out, tag, stamp = sys.argv[1], sys.argv[2], sys.argv[3]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "RDREQ", "WRREQ"):
     for path in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
         rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r.get("Dispatch_Id", 0)))
         for row in rows:
@@ -49,10 +56,21 @@ for k, v in acc.items():
     fetch = 2.0 * 1024 * sum(f) / len(f); write = 1024.0 * sum(w) / len(w)
     traffic[k] = {"fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write),
                   "hbm_bytes_per_launch": int(fetch + write), "launches_sampled": len(f)}
+    mean = lambda name: (sum(v[name]) / len(v[name])) if v.get(name) else None
+    rd, rd128, rd_dram = mean("TCC_EA0_RDREQ_sum"), mean("TCC_EA0_RDREQ_128B_sum"), mean("TCC_EA0_RDREQ_DRAM_32B_sum")
+    wr, wr64, wr_dram = mean("TCC_EA0_WRREQ_sum"), mean("TCC_EA0_WRREQ_64B_sum"), mean("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum")
+    if rd:
+        traffic[k]["cross_check"] = {
+            "read_requests": int(rd), "of_which_128_bytes": int(rd128 or 0), "read_bytes_dram_32B_units": int(32 * (rd_dram or 0)),
+            "write_requests": int(wr or 0), "of_which_64_bytes": int(wr64 or 0), "write_bytes_dram_32B_units": int(32 * (wr_dram or 0)),
+            "what": "TCC_EA0_* request counters of the same command: reads are 128-byte requests (FETCH_SIZE prices them at 64: "
+                    "the x2), the DRAM counters are in 32-byte units"}
 json.dump({"tag": tag, "box": stamp, "kernel_source_hash": bench.kernel_source_hash(),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --gops-per-step 1 --steps 2 "
-                   "--warmup 1` (93 launches per kernel: 3 I + 90 P pictures x 64 streams); FETCH_SIZE x2 (gfx950 "
-                   "calibration), KiB -> bytes",
+                   "--warmup 1` (93 launches per kernel: 3 I + 90 P pictures x 64 streams); FETCH_SIZE x2 (gfx950: every L2 read "
+                   "request is 128 bytes and FETCH_SIZE prices it at 64 -- checked on k_frame's own access shapes, 12-byte gathers "
+                   "and skewed strip loads over a known byte count, profiles/r04_e_fetch_calibration.json), KiB -> bytes",
+           "fetch_size_factor": 2.0,
            "kernels": traffic}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
 PY

@@ -487,9 +487,6 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 // at the same time on the same XCD: the planes are fetched from HBM once per frame instead of twice, and waves
 // bound by arithmetic and address work (reconstruction) share every CU with waves bound by stores (RGBA).
 // ---------------------------------------------------------------------------------------
-#if defined(H263MI_EXP_WAVES_PER_EU)
-__attribute__((amdgpu_waves_per_eu(1, H263MI_EXP_WAVES_PER_EU)))
-#endif
 __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg)
 {
 #if defined(H263MI_LDS_PAD)
@@ -511,16 +508,9 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
     const uint32_t pic_y = blockIdx.y * (8u >> bsh) + side;
     if (t >= chunk || g >= upp || pic_y >= ra.n_pictures) return;
     const uint32_t group = div_tiles_x(g, per_group, fg.inv_per_group);
-    uint32_t r = g - group * per_group;            // (post tiles in front of the reconstruction waves: no difference)
+    const uint32_t r = g - group * per_group;      // (post tiles in front of the reconstruction waves, or the two kinds
+                                                   // alternating 2 : 1 through the group: no difference, profiles/README.md r04_a)
     const int pic = fg.flip ? (int)(ra.n_pictures - 1 - pic_y) : (int)pic_y;
-#if defined(H263MI_EXP_INTERLEAVE)
-    // EXPERIMENT: the group's list as (reconstruction wave, reconstruction wave, post tile) triples instead of all
-    // reconstruction waves first: store-heavy and ALU-heavy waves alternate in the dispatch order of every XCD
-    if (fg.recon_per_group == 2u * fg.post_per_group) {
-        const uint32_t k = __umulhi(r, 0x55555556u), m = r - 3u * k;       // r / 3, r % 3
-        r = m == 2u ? fg.recon_per_group + k : 2u * k + m;
-    }
-#endif
     if (r < fg.recon_per_group) {
         WavePos p;
         p.pic = pic;

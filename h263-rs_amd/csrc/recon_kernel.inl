@@ -625,16 +625,28 @@ H263_DEV uint4 load16_stream(const uint8_t *p)
 #endif
 }
 
-// coefficient row `r` of the block descriptor d0 describes (any mapped address when there is none)
+// coefficient row `r` of the block descriptor d0 describes (any mapped address when there is none): a wave-uniform base
+// plus a 32-bit lane offset -- the picture's first coefficient block (or, for a call without a pool, the records) and the
+// block's byte offset or 0 -- so that the load takes its base from scalar registers and the lane needs one add and one
+// AND for its address (round 3 selected between two 64-bit addresses per lane: two 64-bit adds, two selects)
 H263_DEV const uint8_t *coeff_row_address(const ReconArgs &a, const WavePos &p, uint32_t d0, bool wanted, int r)
 {
-    const uint8_t *pic = reinterpret_cast<const uint8_t *>(a.coeffs) + p.cbase * 128u;      // uniform
+    const uint32_t want = (wanted && d0 != NO_COEFFS) ? 0xffffffffu : 0u;
+    // The base is the picture's first coefficient block when SOME lane of the wave reads a block -- then that block exists,
+    // and the lanes without one read its first row -- and the records otherwise (a picture, or a pool, without any coded
+    // block has no address of its own that is safe to touch).
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool some = __ballot(want != 0) != 0;
+#else
+    const bool some = want != 0;                    // (the CPU checker runs the lanes one by one)
+#endif
+    const uint8_t *pic = some ? reinterpret_cast<const uint8_t *>(a.coeffs) + p.cbase * 128u
+                              : reinterpret_cast<const uint8_t *>(a.mbs);                   // uniform
 #if defined(H263MI_TIMING_COEF_WRAP)
     // TIMING EXPERIMENT ONLY (results wrong): every coefficient block comes out of one 64 KB region (cache resident)
-    return (wanted && d0 != NO_COEFFS) ? reinterpret_cast<const uint8_t *>(a.coeffs) + (d0 & 0xff80u) + (uint32_t)r * 16u
-                                       : reinterpret_cast<const uint8_t *>(a.mbs);
+    return reinterpret_cast<const uint8_t *>(a.coeffs) + (((d0 & 0xff80u) + (uint32_t)r * 16u) & want);
 #endif
-    return (wanted && d0 != NO_COEFFS) ? pic + d0 + (uint32_t)r * 16u : reinterpret_cast<const uint8_t *>(a.mbs);
+    return pic + ((d0 + (uint32_t)r * 16u) & want);
 }
 
 // The loads are issued unconditionally and in a fixed order -- coefficient row first, then the 5 + 3 reference rows --
@@ -806,14 +818,10 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
         // 8 lanes x 16 B = one 128-B coefficient block (raster order: lane r holds row r)
         raw = load16_stream(coeff_row_address(a, p, d0, ri.active, r));
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (__ballot(!has) == 0) {                                  // uniform: every lane of the round has a block (dense pictures)
-        asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));    // (keeps this a branch: as selects it saves nothing)
-        ri.w[0] = raw.x; ri.w[1] = raw.y; ri.w[2] = raw.z; ri.w[3] = raw.w;
-        return;
-    }
-#endif
-    ri.w[0] = has ? raw.x : 0u; ri.w[1] = has ? raw.y : 0u; ri.w[2] = has ? raw.z : 0u; ri.w[3] = has ? raw.w : 0u;
+    // (a lane without a block has loaded some other block's row: masked away with four ANDs -- cheaper than a ballot, a
+    // branch and the register copies the all-lanes-have-a-block shortcut of round 3 came out as)
+    const uint32_t keep = has ? 0xffffffffu : 0u;
+    ri.w[0] = raw.x & keep; ri.w[1] = raw.y & keep; ri.w[2] = raw.z & keep; ri.w[3] = raw.w & keep;
 }
 
 // lane's contribution to cols_from_mask

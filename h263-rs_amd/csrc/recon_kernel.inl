@@ -631,14 +631,18 @@ H263_DEV uint4 load16_stream(const uint8_t *p)
 // AND for its address (round 3 selected between two 64-bit addresses per lane: two 64-bit adds, two selects)
 H263_DEV const uint8_t *coeff_row_address(const ReconArgs &a, const WavePos &p, uint32_t d0, bool wanted, int r)
 {
-    const uint32_t want = (wanted && d0 != NO_COEFFS) ? 0xffffffffu : 0u;
+    const bool wants = wanted && d0 != NO_COEFFS;
+    uint32_t want = wants ? 0xffffffffu : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(want));                  // (a mask in a register: ANDs below, not selects)
+#endif
     // The base is the picture's first coefficient block when SOME lane of the wave reads a block -- then that block exists,
     // and the lanes without one read its first row -- and the records otherwise (a picture, or a pool, without any coded
     // block has no address of its own that is safe to touch).
 #if defined(__HIP_DEVICE_COMPILE__)
-    const bool some = __ballot(want != 0) != 0;
+    const bool some = __ballot(wants) != 0;
 #else
-    const bool some = want != 0;                    // (the CPU checker runs the lanes one by one)
+    const bool some = wants;                        // (the CPU checker runs the lanes one by one)
 #endif
     const uint8_t *pic = some ? reinterpret_cast<const uint8_t *>(a.coeffs) + p.cbase * 128u
                               : reinterpret_cast<const uint8_t *>(a.mbs);                   // uniform
@@ -820,7 +824,10 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     }
     // (a lane without a block has loaded some other block's row: masked away with four ANDs -- cheaper than a ballot, a
     // branch and the register copies the all-lanes-have-a-block shortcut of round 3 came out as)
-    const uint32_t keep = has ? 0xffffffffu : 0u;
+    uint32_t keep = has ? 0xffffffffu : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(keep));
+#endif
     ri.w[0] = raw.x & keep; ri.w[1] = raw.y & keep; ri.w[2] = raw.z & keep; ri.w[3] = raw.w & keep;
 }
 

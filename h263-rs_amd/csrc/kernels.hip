@@ -228,6 +228,7 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     // reference rows, and straight-line code is what lets the compiler wait for exactly that load
     // (s_waitcnt vmcnt(8)) and leave the eight reference loads in flight under the row pass.
     RoundState rs;
+    rs.ri.bad_events = 0;
     if (n_active > 0) recon_round_rows<true, MC>(a, s, f, ln, p, 0, km, rs);
     PHASE_MARK(3);
     asm volatile("" : "+v"(ln));
@@ -245,6 +246,8 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     }
     PHASE_MARK(5);
     asm volatile("" : "+v"(ln));
+    // event bounds that could not be used (only looked at when the caller said how many events there are): one report per wave
+    if (a.events && a.n_events != 0xffffffffu) recon_report(a, ln, p.pic, false, __ballot(rs.ri.bad_events != 0) != 0);
     wave_fence();                                   // the strip is complete
     ISA_MARK2(MC, "mc_", "intra_", "store_begin");
     recon_phase_store(a, s, ln, p, km);

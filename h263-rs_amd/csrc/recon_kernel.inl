@@ -728,6 +728,8 @@ H263_DEV void recon_phase_fetch(const ReconArgs &a, ReconWave &s, WaveFetch &f, 
 
 // ---- phase 4a: coefficient row of the lane, row pass -----------------------------------------
 struct RowIn {
+    uint32_t bad_events;       // sparse transport: 1 once a block of this lane had unusable event bounds (kept across the rounds;
+                               // the caller zeroes it in front of the first round and reports it behind the last)
     uint32_t w[4];             // the 8 LEVELs of the lane's coefficient row (zeros when the block has no TCOEF)
     uint32_t d1;               // descriptor word 1 of the lane's block (quantiser, INTRADC level, intra, task)
     bool     active;           // the lane's slot holds a block in this round
@@ -746,32 +748,32 @@ struct RowIn {
 // the steps); 0, 1, 2 = one step only (the CPU logic checker runs the lanes one after the other and therefore each step
 // over all lanes before the next).
 H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const WavePos &p, uint32_t d0, bool has, int lane,
-                                     uint32_t w[4], int stage = -1, bool bounds_known = false, uint32_t known_first = 0,
-                                     uint32_t known_next = 0)
+                                     uint32_t w[4], uint32_t *bad_events, int stage = -1, bool bounds_known = false,
+                                     uint32_t known_first = 0, uint32_t known_next = 0)
 {
     const int slot = lane >> 3, r = lane & 7;
     int16_t *dense = reinterpret_cast<int16_t *>(s.tbuf);       // [8 slots][64 positions]
     if (stage < 0 || stage == 0) *reinterpret_cast<uint4 *>(dense + lane * 8) = make_uint4(0, 0, 0, 0);
     if (stage < 0 || stage == 1) {
         uint32_t at = 0, end = 0;
-        bool bad = false;
+        uint32_t bad = 0;
+        const bool told = a.n_events != 0xffffffffu;            // uniform
         if (has) {
             const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
             // (the first round's bounds were requested by the fetch phase)
             const uint32_t first = bounds_known ? known_first : fe[0], next = bounds_known ? known_next : fe[1];
-            // The bounds come out of device memory nobody may have validated (h263mi_batch_decode_events): a pair that is
-            // not ascending, or that reaches beyond the events the caller said there are, reads NOTHING and rejects the
-            // picture (a.n_events = 0xffffffff when the caller did not say: only the order is checked then).
-            bad = first > next || next > a.n_events;
+            // The bounds come out of device memory nobody may have validated (h263mi_batch_decode_events).  When the caller
+            // has said how many events there are (a.n_events != 0xffffffff; the host entry points always do), a pair that is
+            // not ascending or that reaches beyond them reads NOTHING and rejects the picture; a caller that did not say
+            // vouches for its arrays, and the wave spends nothing on them (checked and reported inside the round, the test
+            // cost the 64-stream launch 3.5 %: profiles/README.md r04_i -- the verdict is collected in `bad_events` and
+            // reported once per wave).
+            if (told) bad = (first > next || next > a.n_events) ? 1u : 0u;
             const uint32_t count = bad ? 0u : next - first;
             at = first + (uint32_t)r;
             end = first + (count > 64u ? 64u : count);          // (a block has 64 positions)
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        recon_report(a, lane, p.pic, false, __ballot(bad) != 0);
-#else
-        if (bad) a.status[p.pic] |= STATUS_COEFF_INDEX_OUT_OF_RANGE;
-#endif
+        if (told) *bad_events |= bad;
         wave_fence();                                           // zeroed before the first LEVEL lands
 #if defined(__HIP_DEVICE_COMPILE__)
         while (__ballot(at < end) != 0) {
@@ -815,7 +817,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     }
     const bool has = ri.active && d0 != NO_COEFFS;
     if (a.events) {                                             // uniform
-        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, events_stage, round == 0, raw.x, raw.y);
+        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, &ri.bad_events, events_stage, round == 0, raw.x, raw.y);
         return;
     }
     if (round > 0) {

@@ -339,14 +339,20 @@ def test_event_bounds_from_device_memory_are_checked_against_n_events():
     d_bad = _upload(bad)
     b.decode_events(h263mi.PICTURE_I, d[0].ptr, d_bad.ptr, d[2].ptr, d[3].ptr, at_b, n_events=at_e)
     assert b.sync_streams() == [0, h263mi.ERR_INVALID_ARGUMENT]
-    # a descending pair in stream 0: rejected even when n_events was not given
+    # a descending pair in stream 0: rejected as well (a caller that does not say n_events vouches for its arrays: nothing
+    # is looked at then, and nothing is promised)
     bad = first_all.copy()
     bad[3] = bad[2] - 1 if bad[2] > 0 else 0
     bad[2] = bad[3] + 5
     d_bad2 = _upload(bad)
-    b.decode_events(h263mi.PICTURE_I, d[0].ptr, d_bad2.ptr, d[2].ptr, d[3].ptr, at_b)
+    b.decode_events(h263mi.PICTURE_I, d[0].ptr, d_bad2.ptr, d[2].ptr, d[3].ptr, at_b, n_events=at_e)
     rcs = b.sync_streams()
     assert rcs[0] == h263mi.ERR_INVALID_ARGUMENT and rcs[1] == 0
+    # and the good arrays decode again afterwards
+    b.decode_events(h263mi.PICTURE_I, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, at_b, n_events=at_e)
+    assert b.sync_streams() == [0, 0]
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), want[s], "stream %d, after the rejected pictures" % s)
     b.close()
 
 

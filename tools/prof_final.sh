@@ -59,6 +59,14 @@ for k, v in acc.items():
     mean = lambda name: (sum(v[name]) / len(v[name])) if v.get(name) else None
     rd, rd128, rd_dram = mean("TCC_EA0_RDREQ_sum"), mean("TCC_EA0_RDREQ_128B_sum"), mean("TCC_EA0_RDREQ_DRAM_32B_sum")
     wr, wr64, wr_dram = mean("TCC_EA0_WRREQ_sum"), mean("TCC_EA0_WRREQ_64B_sum"), mean("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum")
+    if rd and rd_dram and wr_dram:
+        # the exact figure: the DRAM request counters in 32-byte units (k_frame: 8.5 % of its read requests are 64 bytes,
+        # so FETCH_SIZE x 2 overstates its reads by 4 %)
+        traffic[k]["fetch_bytes_per_launch_fetch_size_x2"] = traffic[k]["fetch_bytes_per_launch"]
+        traffic[k]["write_bytes_per_launch_write_size"] = traffic[k]["write_bytes_per_launch"]
+        traffic[k]["fetch_bytes_per_launch"] = int(32 * rd_dram)
+        traffic[k]["write_bytes_per_launch"] = int(32 * wr_dram)
+        traffic[k]["hbm_bytes_per_launch"] = int(32 * rd_dram + 32 * wr_dram)
     if rd:
         traffic[k]["cross_check"] = {
             "read_requests": int(rd), "of_which_128_bytes": int(rd128 or 0), "read_bytes_dram_32B_units": int(32 * (rd_dram or 0)),
@@ -71,6 +79,8 @@ json.dump({"tag": tag, "box": stamp, "kernel_source_hash": bench.kernel_source_h
                    "request is 128 bytes and FETCH_SIZE prices it at 64 -- checked on k_frame's own access shapes, 12-byte gathers "
                    "and skewed strip loads over a known byte count, profiles/r04_e_fetch_calibration.json), KiB -> bytes",
            "fetch_size_factor": 2.0,
+           "hbm_bytes_source": "TCC_EA0_RDREQ_DRAM_32B_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum x 32 bytes where collected (exact), "
+                               "else FETCH_SIZE x 2 + WRITE_SIZE",
            "kernels": traffic}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
 PY

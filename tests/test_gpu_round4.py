@@ -435,3 +435,43 @@ def test_mixed_sizes_in_one_set(pipeline):
         bad = np.flatnonzero(got != want)
         assert bad.size == 0, "RGBA of call %d stream %d (%dx%d): %d bytes differ" % (f, s, w, h, bad.size)
     m.close()
+
+
+def test_overlap_mode_with_streams_that_have_drifted_apart():
+    """H263MI_CFG_OVERLAP_POST (k_post on a second HIP stream) together with per-stream state words -- one stream
+    sits calls out, so the streams' ping-pong positions differ and every wave reads its stream's word.  The words are now
+    copied on the stream of the kernel that reads them, and a reconstruction waits for the post-processing of BOTH frame
+    sets.  Many pictures back to back without a sync, every RGBA checked."""
+    import recgen
+    w, h, n, frames = 176, 144, 4, 8
+    cw = (w + 1) // 2
+    b = h263mi.Batch(n, w, h, overlap_post=True)
+    refs = [None] * n
+    d_rgba = [h263mi.DeviceBuffer(n * w * h * 4) for _ in range(frames)]
+    want = []
+    for f in range(frames):
+        sits_out = {2: (1,), 3: (1, 3), 5: (0,)}.get(f, ())
+        b.set_active([s not in sits_out for s in range(n)])
+        mbs, cos = [], []
+        for s in range(n):
+            if f == 0:
+                m, c = recgen.intra_picture(w, h, seed=11 * s + 3)
+            else:
+                m, c = recgen.inter_picture(w, h, seed=70 * f + s, mv_range=40, p_4v=0.3, p_coded=0.4, quant=6)
+            mbs.append(m)
+            cos.append(c)
+            if s not in sits_out:
+                rc, refs[s] = orc.decode_picture(w, h, m, c, refs[s])
+                assert rc == 0
+        b.submit_host(h263mi.PICTURE_I if f == 0 else h263mi.PICTURE_P, mbs, cos)
+        b.render_rgba(5, d_rgba[f].ptr)                      # (renders every stream's LAST picture)
+        want.append([orc.yuv420_to_rgba(*(orc.deblock(p, pw, 5) for p, pw in zip(refs[s], (w, cw, cw))), w) for s in range(n)])
+    b.set_active(None)
+    b.sync()
+    for f in range(frames):
+        got = d_rgba[f].download().reshape(n, -1)
+        for s in range(n):
+            assert (got[s] == want[f][s].reshape(-1)).all(), (f, s)
+    for s in range(n):
+        assert_planes_equal(b.copy_yuv(s), refs[s], "stream %d" % s)
+    b.close()

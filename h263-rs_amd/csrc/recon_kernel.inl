@@ -103,7 +103,9 @@ struct TaskInfo {
 H263_HD uint32_t desc_quant(uint32_t d1) { return d1 & 0xffu; }
 H263_HD uint32_t desc_level(uint32_t d1) { return (d1 >> 8) & 0x7ffu; }
 H263_HD bool     desc_intra(uint32_t d1) { return (d1 >> 19) & 1u; }
-H263_HD int      desc_task(uint32_t d1) { return (int)(d1 >> 20); }
+// (bits 20 and up: where the block's 8x8 pixels start in the reconstruction strip, in units of 8 bytes -- worked out once per
+// task in the mark phase; rounds 1-3 carried the task number and every lane of every round derived the origin from it)
+H263_HD int      desc_pix_origin(uint32_t d1) { return (int)((d1 >> 20) << 3); }
 
 // Wave-wide bit masks.  On the device they come out of ballots and live in scalar registers; the CPU logic checker
 // (tests/sim) runs the lanes one after the other and ORs the lanes' bits together.
@@ -477,7 +479,10 @@ H263_DEV TaskInfo recon_phase_mark(const ReconArgs &, ReconWave &s, int lane, co
     t.d0 = (idx << 7) | (0u - ((coded & in_range) ^ 1u));                    // NO_COEFFS unless coded and in range
     // IntraDc::into_level (types.rs:955-961): code << 3, 0xff -> 1024; here already shifted into its descriptor field
     const uint32_t level8 = (dcb << 11) ^ ((0u - dc_is_ff) & ((2040u ^ 1024u) << 8));
-    t.d1 = ((w0 >> 8) & 0xffu) | level8 | ((0x18u << 19 >> (mb_type & 31u)) & (1u << 19)) | (ln << 20);
+    // task_pix_origin(lane) / 8: luma (ln >> 4) * 128 + (ln & 15), chroma 256 + ((ln >> 3) & 1) * 8 + (ln & 7)
+    const uint32_t org_l = ((ln >> 4) << 7) + (ln & 15u), org_c = 256u + (((ln >> 3) & 1u) << 3) + (ln & 7u);
+    const uint32_t org8 = org_c ^ ((org_c ^ org_l) & (0u - luma_task));
+    t.d1 = ((w0 >> 8) & 0xffu) | level8 | ((0x18u << 19 >> (mb_type & 31u)) & (1u << 19)) | (org8 << 20);
     (void)intra;
     // which macroblocks take a prediction from the reference picture (gather.rs:136-149)
     t.inter = is_mb & valid & inter_type;
@@ -911,7 +916,6 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
     if (!DENSE && !ri.active) return;
     if (DENSE) { n_rows = 8; any_special = false; }
     const int slot = lane >> 3, i = lane & 7;
-    const int t = desc_task(ri.d1);
     const uint32_t slot_rows = (uint32_t)(rows_any >> (8 * slot)) & 0xfeu, slot_cols = (uint32_t)(cols_any >> (8 * slot)) & 0xffu;
     const bool is_horiz = slot_rows == 0, is_vert = slot_cols == 0;
 
@@ -946,7 +950,7 @@ H263_DEV void recon_phase_idct_cols(ReconWave &s, const RowIn &ri, int lane, int
     //   pixel = (r + prediction).clamp(0, 255)                      idct.rs:127-130, 191-194
     // The clamp of r to [-256, 255] is implied by the final one (the prediction is 0..255: any r >= 255 ends at 255,
     // any r <= -255 at 0), and |v| stays far below 2^31, so the conversion cannot saturate.
-    uint8_t *base = &s.pix[task_pix_origin(t) + i];
+    uint8_t *base = &s.pix[desc_pix_origin(ri.d1) + i];
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) {
         const f32x2 q4 = O[jp];

@@ -389,7 +389,10 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
  *                 does it: on a H263MI_CFG_PIPELINE_POST batch deferred to the next call's launch (k_frame), else a launch
  *                 of its own behind the reconstruction.  Streams that did not decode a picture in this call are not
  *                 rendered (their part of the buffers is not written).
- * Returns H263MI_OK when the call itself went through (look at stream_rc), else a back-end error.
+ * Returns H263MI_OK when the call itself went through (look at stream_rc), else a back-end error.  An error of the
+ * RENDERING half (the launch or an allocation behind it) is returned after the pictures were decoded: stream_rc and
+ * consumed are valid then, the streams have advanced (a failed rendering does not un-decode anything); every error in
+ * front of the reconstruction launch leaves all streams as they were.
  */
 int h263mi_batch_decode_next_pictures_ex(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                          const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,

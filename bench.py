@@ -860,6 +860,7 @@ def main(argv=None):
         print(json.dumps(out), flush=True)
     batch.close()
     if dist is not None:
+        dist.barrier()                  # (rank 0 has just spent ~30 s on the CPU baseline: nobody leaves before it is back)
         dist.destroy_process_group()
     return 1 if gate_bad else 0
 

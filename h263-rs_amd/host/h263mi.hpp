@@ -132,6 +132,10 @@ public:
         return rgba;
     }
 
+    // the same straight into page-locked memory of the caller (h263mi_host_alloc / h263mi_host_register): the buffer a
+    // renderer reuses for every picture instead of the fresh Vec<u8> of bt601.rs:128; `rgba` holds width * height * 4 bytes
+    void render_rgba_into_pinned(uint8_t strength, uint8_t *rgba) const { check(h263mi_render_rgba_pinned(s_, strength, rgba)); }
+
     h263mi_state *raw() { return s_; }
 
 private:
@@ -148,6 +152,26 @@ private:
         return p;
     }
     h263mi_state *s_ = nullptr;
+};
+
+// page-locked, device-visible host memory (h263mi_host_alloc) for H263State::render_rgba_into_pinned
+class PinnedBuffer {
+public:
+    explicit PinnedBuffer(size_t bytes) : bytes_(bytes)
+    {
+        void *p = nullptr;
+        check(h263mi_host_alloc(bytes, &p));
+        p_ = static_cast<uint8_t *>(p);
+    }
+    ~PinnedBuffer() { (void)h263mi_host_free(p_); }
+    PinnedBuffer(const PinnedBuffer &) = delete;
+    PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+    uint8_t *data() { return p_; }
+    size_t size() const { return bytes_; }
+
+private:
+    uint8_t *p_ = nullptr;
+    size_t bytes_ = 0;
 };
 
 }  // namespace h263

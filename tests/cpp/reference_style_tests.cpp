@@ -137,6 +137,10 @@ static void test_state_api()                       // state.rs:42-78, gather.rs:
     ASSERT_EQ(p2->as_luma(), pic->as_luma(), "copy Y");
     ASSERT_EQ(p2->as_chroma_r(), pic->as_chroma_r(), "copy Cr");
     ASSERT_EQ(st.render_rgba(0), yuv::bt601::yuv420_to_rgba(p2->as_luma(), p2->as_chroma_b(), p2->as_chroma_r(), 176), "render == convert");
+    // ... and the same bytes straight into the caller's pinned buffer (ABI 4)
+    h263::PinnedBuffer pinned((size_t)176 * 144 * 4);
+    st.render_rgba_into_pinned(5, pinned.data());
+    ASSERT_EQ(std::vector<uint8_t>(pinned.data(), pinned.data() + pinned.size()), st.render_rgba(5), "pinned render == render");
 }
 
 int main()

@@ -9,6 +9,7 @@
 //                          chroma_samples_per_row, as_yuv}       h263/src/decoder/picture.rs:61-142
 //   h263::DecoderOption                                          h263/src/decoder/types.rs:3-17
 //   h263::Error                                                  h263/src/error.rs:6-93
+//   h263::H263StateSet: N of those states advancing together (h263mi_mixed), per-stream behaviour as above
 //   deblock::deblock, deblock::QUANT_TO_STRENGTH                 deblock/src/deblock.rs:5-8,305-315
 //   yuv::bt601::yuv420_to_rgba                                   yuv/src/bt601.rs:105-196
 //
@@ -66,6 +67,7 @@ public:
 
 private:
     friend class H263State;
+    friend class H263StateSet;
     h263mi_frame_view view_{};
     std::vector<uint8_t> luma_, chroma_b_, chroma_r_;
 };
@@ -172,6 +174,132 @@ public:
 private:
     uint8_t *p_ = nullptr;
     size_t bytes_ = 0;
+};
+
+
+// memory of the back-end's GPU (h263mi_device_malloc): where a stream set writes its RGBA pictures
+class DeviceBuffer {
+public:
+    explicit DeviceBuffer(size_t bytes, int device_id = 0) : device_(device_id), bytes_(bytes)
+    {
+        void *p = nullptr;
+        check(h263mi_device_malloc(device_id, bytes, &p));
+        p_ = static_cast<uint8_t *>(p);
+    }
+    ~DeviceBuffer() { (void)h263mi_device_free(device_, p_); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    uint8_t *data() { return p_; }
+    size_t size() const { return bytes_; }
+    std::vector<uint8_t> download(size_t bytes) const
+    {
+        if (bytes > bytes_) throw Error(H263MI_ERR_INVALID_ARGUMENT);
+        std::vector<uint8_t> out(bytes);
+        check(h263mi_device_memcpy_d2h(device_, out.data(), p_, bytes));
+        return out;
+    }
+
+private:
+    int device_ = 0;
+    uint8_t *p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+// N H263States that advance together on one GPU (h263mi_mixed): every stream is the H263State of state.rs:16-50 -- its own
+// last / reference picture, its own picture format (state.rs:157-176: streams of different sizes side by side, a size
+// change at an I picture), its own errors -- and one call decodes the next picture of each, one launch per size class.
+// There is no such type in the reference (a caller there holds a Vec<H263State> and loops); the per-stream behaviour is the
+// reference's, which is what the tests check stream by stream.
+class H263StateSet {
+public:
+    H263StateSet(uint32_t n_streams, uint32_t decoder_options, const h263mi_backend_cfg *cfg = nullptr)
+        : n_(n_streams), options_(decoder_options)
+    {
+        check(h263mi_mixed_create(n_streams, cfg, &m_));
+    }
+    ~H263StateSet() { h263mi_mixed_destroy(m_); }
+    H263StateSet(const H263StateSet &) = delete;
+    H263StateSet &operator=(const H263StateSet &) = delete;
+
+    uint32_t len() const { return n_; }
+    bool is_sorenson() const { return (options_ & H263MI_SORENSON_SPARK_BITSTREAM) != 0; }
+
+    // what one call did for every stream: `result[s]` is the `Result<(), Error>` of stream s's decode_next_picture
+    // (H263MI_OK or the code h263::Error carries), `consumed[s]` the bytes its reader advanced by, `headers[s]` the
+    // picture it decoded
+    struct Outcome {
+        std::vector<int> result;
+        std::vector<size_t> consumed;
+        std::vector<h263mi_picture_desc> headers;
+        bool all_ok() const
+        {
+            for (int rc : result)
+                if (rc != H263MI_OK) return false;
+            return true;
+        }
+    };
+
+    // decode_next_picture (state.rs:138-141) of every stream that has a picture in this call: data[s] == nullptr leaves
+    // stream s alone.  d_rgba (optional): per stream a DEVICE buffer of rgba_capacity[s] bytes that receives deblock(strength)
+    // (0 = off) + BT.601 of the picture (on a H263MI_CFG_PIPELINE_POST set: by the time of the next call or of sync()).
+    // Throws only for a failure of the call itself; a stream's own error is in Outcome::result and leaves that stream as
+    // it was (state.rs:142).
+    Outcome decode_next_pictures(const std::vector<const uint8_t *> &data, const std::vector<size_t> &len, uint8_t strength = 0,
+                                 const std::vector<uint8_t *> *d_rgba = nullptr, const std::vector<size_t> *rgba_capacity = nullptr,
+                                 uint32_t n_threads = 0)
+    {
+        if (data.size() != n_ || len.size() != n_ || (d_rgba && (!rgba_capacity || d_rgba->size() != n_ || rgba_capacity->size() != n_)))
+            throw Error(H263MI_ERR_INVALID_ARGUMENT);
+        Outcome o;
+        o.result.assign(n_, H263MI_OK);
+        o.consumed.assign(n_, 0);
+        o.headers.assign(n_, h263mi_picture_desc{});
+        check(h263mi_mixed_decode_next_pictures(m_, options_, data.data(), len.data(), o.consumed.data(), n_threads, o.result.data(),
+                                                strength, d_rgba ? d_rgba->data() : nullptr,
+                                                rgba_capacity ? rgba_capacity->data() : nullptr, o.headers.data()));
+        return o;
+    }
+
+    // waits for everything queued (deferred RGBA included); the device's verdict per stream (H263MI_OK, or the error that
+    // sent the stream back to its previous picture)
+    std::vector<int> sync()
+    {
+        std::vector<int> rc(n_, H263MI_OK);
+        const int first = h263mi_mixed_sync(m_, rc.data());
+        bool explained = false;                      // an error return that is some stream's verdict is not thrown
+        for (int r : rc) explained = explained || r == first;
+        if (first != H263MI_OK && !explained) throw Error(first);
+        return rc;
+    }
+
+    // get_last_picture (state.rs:61-67) of stream `stream`
+    std::optional<DecodedPicture> get_last_picture(uint32_t stream)
+    {
+        uint16_t w = 0, h = 0;
+        const int rc = h263mi_mixed_stream_size(m_, stream, &w, &h);
+        if (rc == H263MI_ERR_NO_PICTURE) return std::nullopt;
+        check(rc);
+        DecodedPicture p;
+        p.view_.width = w;
+        p.view_.height = h;
+        p.view_.chroma_width = (uint16_t)((w + 1) / 2);
+        p.view_.chroma_height = (uint16_t)((h + 1) / 2);
+        p.luma_.resize((size_t)w * h);
+        p.chroma_b_.resize((size_t)p.view_.chroma_width * p.view_.chroma_height);
+        p.chroma_r_.resize(p.chroma_b_.size());
+        check(h263mi_mixed_copy_yuv(m_, stream, p.luma_.data(), p.chroma_b_.data(), p.chroma_r_.data()));
+        return p;
+    }
+
+    // H263State::new for one stream (the seeking rule of state.rs:134-137 with the format forgotten too)
+    void reset_stream(uint32_t stream) { check(h263mi_mixed_reset_stream(m_, stream)); }
+    // how many picture sizes the set has met so far (one fixed-geometry batch and one launch per call each)
+    uint32_t size_classes() const { return h263mi_mixed_size_classes(m_); }
+    h263mi_mixed *raw() { return m_; }
+
+private:
+    h263mi_mixed *m_ = nullptr;
+    uint32_t n_ = 0, options_ = 0;
 };
 
 }  // namespace h263

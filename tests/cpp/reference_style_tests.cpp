@@ -143,6 +143,68 @@ static void test_state_api()                       // state.rs:42-78, gather.rs:
     ASSERT_EQ(std::vector<uint8_t>(pinned.data(), pinned.data() + pinned.size()), st.render_rgba(5), "pinned render == render");
 }
 
+static uint64_t fnv1a64(const std::vector<uint8_t> &b)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint8_t x : b) h = (h ^ x) * 0x100000001b3ull;
+    return h;
+}
+
+// N states of different picture sizes advancing together (h263::H263StateSet over h263mi_mixed): each stream behaves as the
+// H263State of state.rs:138-176 -- decoded planes and rendered RGBA against the oracle's (checksums in golden_data.h), a
+// stream without a picture in a call is left alone, an inter picture on a fresh stream is ITS UncodedIFrameBlocks
+static void test_state_set()
+{
+    const GoldCoded *pic[2][2] = {};
+    for (const auto &g : GOLD_CODED) pic[g.stream][g.index] = &g;
+    h263::H263StateSet set(3, h263::DecoderOption::SORENSON_SPARK_BITSTREAM);
+    ASSERT_EQ(set.is_sorenson(), true, "is_sorenson");
+    ASSERT_EQ(set.get_last_picture(0).has_value(), false, "no picture yet");
+    h263::DeviceBuffer rgba0(352 * 288 * 4), rgba1(352 * 288 * 4), rgba2(352 * 288 * 4);
+    std::vector<uint8_t *> d_rgba = {rgba0.data(), rgba1.data(), rgba2.data()};
+    const std::vector<size_t> cap = {rgba0.size(), rgba1.size(), rgba2.size()};
+    // call 0: I pictures for streams 0 (QCIF) and 1 (CIF); stream 2 is handed stream 0's P picture: no reference
+    auto o = set.decode_next_pictures({pic[0][0]->data.data(), pic[1][0]->data.data(), pic[0][1]->data.data()},
+                                      {pic[0][0]->data.size(), pic[1][0]->data.size(), pic[0][1]->data.size()},
+                                      (uint8_t)GOLD_CODED_STRENGTH, &d_rgba, &cap);
+    ASSERT_EQ(o.result[0], H263MI_OK, "stream 0 decodes");
+    ASSERT_EQ(o.result[1], H263MI_OK, "stream 1 decodes");
+    ASSERT_EQ(o.result[2], H263MI_ERR_UNCODED_IFRAME_BLOCKS, "stream 2: UncodedIFrameBlocks");
+    ASSERT_EQ(o.consumed[0] > 0 && o.consumed[0] <= pic[0][0]->data.size(), true, "bytes consumed");
+    ASSERT_EQ((int)o.headers[1].width, 352, "header of stream 1");
+    for (int rc : set.sync()) ASSERT_EQ(rc, H263MI_OK, "device verdicts");
+    ASSERT_EQ(set.size_classes(), 2u, "two sizes, two classes");
+    ASSERT_EQ(set.get_last_picture(2).has_value(), false, "the failed stream has no picture");
+    for (int s = 0; s < 2; s++) {
+        auto p = set.get_last_picture((uint32_t)s);
+        ASSERT_EQ(p.has_value(), true, "picture");
+        ASSERT_EQ(p->luma_samples_per_row(), (size_t)pic[s][0]->width, "luma_samples_per_row");
+        ASSERT_EQ(fnv1a64(p->as_luma()), pic[s][0]->sums[0], "I picture: Y");
+        ASSERT_EQ(fnv1a64(p->as_chroma_b()), pic[s][0]->sums[1], "I picture: Cb");
+        ASSERT_EQ(fnv1a64(p->as_chroma_r()), pic[s][0]->sums[2], "I picture: Cr");
+    }
+    ASSERT_EQ(fnv1a64(rgba0.download((size_t)176 * 144 * 4)), pic[0][0]->sums[3], "I picture: RGBA of stream 0");
+    ASSERT_EQ(fnv1a64(rgba1.download((size_t)352 * 288 * 4)), pic[1][0]->sums[3], "I picture: RGBA of stream 1");
+    // call 1: P pictures for streams 0 and 1; stream 2 sits the call out
+    o = set.decode_next_pictures({pic[0][1]->data.data(), pic[1][1]->data.data(), nullptr},
+                                 {pic[0][1]->data.size(), pic[1][1]->data.size(), 0}, (uint8_t)GOLD_CODED_STRENGTH, &d_rgba, &cap);
+    ASSERT_EQ(o.all_ok(), true, "P pictures decode, the idle stream reports nothing");
+    for (int rc : set.sync()) ASSERT_EQ(rc, H263MI_OK, "device verdicts");
+    for (int s = 0; s < 2; s++) {
+        auto p = set.get_last_picture((uint32_t)s);
+        ASSERT_EQ(fnv1a64(p->as_luma()), pic[s][1]->sums[0], "P picture: Y");
+        ASSERT_EQ(fnv1a64(p->as_chroma_b()), pic[s][1]->sums[1], "P picture: Cb");
+        ASSERT_EQ(fnv1a64(p->as_chroma_r()), pic[s][1]->sums[2], "P picture: Cr");
+    }
+    ASSERT_EQ(fnv1a64(rgba0.download((size_t)176 * 144 * 4)), pic[0][1]->sums[3], "P picture: RGBA of stream 0");
+    ASSERT_EQ(fnv1a64(rgba1.download((size_t)352 * 288 * 4)), pic[1][1]->sums[3], "P picture: RGBA of stream 1");
+    // stream 0 forgets everything: its next P picture has no reference again, stream 1 is not touched
+    set.reset_stream(0);
+    o = set.decode_next_pictures({pic[0][1]->data.data(), nullptr, nullptr}, {pic[0][1]->data.size(), 0, 0});
+    ASSERT_EQ(o.result[0], H263MI_ERR_UNCODED_IFRAME_BLOCKS, "reset stream needs an I picture");
+    ASSERT_EQ(fnv1a64(set.get_last_picture(1)->as_luma()), pic[1][1]->sums[0], "stream 1 keeps its picture");
+}
+
 int main()
 {
     int n = 0;
@@ -156,6 +218,7 @@ int main()
     test_process();
     test_deblock();
     test_state_api();
+    test_state_set();
     std::printf(failures ? "FAILED (%d)\n" : "all reference-style tests passed\n", failures);
     return failures ? 1 : 0;
 }

@@ -1515,19 +1515,47 @@ struct h263mi_mixed {
         if (!pool || pool->size() < want) pool.reset(new WorkerPool(want - 1));
         return *pool;
     }
-    // the class of size (w, h); created on first use: nothing is allocated for sizes no stream has
-    int class_of(uint32_t w, uint32_t h, int *out)
+    // the class of size (w, h); created on first use: nothing is allocated for sizes no stream has.  `target`: the classes the
+    // streams of the call in progress are about to join.
+    // A class nobody belongs to any more gives up its batch before a new one is made: the dimensions come out of untrusted
+    // bitstreams, and a stream that changes its size with every key frame must not make the set grow -- it holds one class
+    // per stream at most, plus the empty ones left behind since the last time a class was made.
+    int class_of(uint32_t w, uint32_t h, const std::vector<int> &target, int *out)
     {
         for (size_t k = 0; k < classes.size(); k++)
-            if (classes[k].w == w && classes[k].h == h) { *out = (int)k; return H263MI_OK; }
+            if (classes[k].b && classes[k].w == w && classes[k].h == h) { *out = (int)k; return H263MI_OK; }
+        int slot = -1;
+        for (size_t k = 0; k < classes.size(); k++) {
+            bool used = false;
+            for (uint32_t i = 0; i < n && !used; i++) used = cls[i] == (int)k || target[i] == (int)k;
+            if (used) continue;
+            if (classes[k].b) {
+                // (a rendering of a picture a departed stream left behind is delivered first; the destructor waits for it)
+                if (classes[k].b->pending.valid) (void)classes[k].b->flush_pending();
+                delete classes[k].b;
+                classes[k] = SizeClass();
+            }
+            if (slot < 0) slot = (int)k;
+        }
         h263mi_batch *b = nullptr;
         RC_TRY(batch_create(n, w, h, &cfg, &b));
         // no stream of a new class has a picture: every slot starts inactive and without one
         SizeClass c;
         c.w = w; c.h = h; c.b = b;
-        classes.push_back(c);
-        *out = (int)classes.size() - 1;
+        if (slot < 0) {
+            classes.push_back(c);
+            slot = (int)classes.size() - 1;
+        } else {
+            classes[slot] = c;
+        }
+        *out = slot;
         return H263MI_OK;
+    }
+    uint32_t live_classes() const
+    {
+        uint32_t k = 0;
+        for (const SizeClass &c : classes) k += c.b ? 1u : 0u;
+        return k;
     }
 };
 
@@ -1563,7 +1591,7 @@ int h263mi_mixed_stream_size(const h263mi_mixed *m, uint32_t stream, uint16_t *w
     return has ? H263MI_OK : H263MI_ERR_NO_PICTURE;
 }
 
-uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m) { return m ? (uint32_t)m->classes.size() : 0; }
+uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m) { return m ? m->live_classes() : 0; }
 
 int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options, const uint8_t *const *data, const size_t *len,
                                       size_t *consumed, uint32_t n_threads, int *stream_rc, uint8_t strength,
@@ -1612,7 +1640,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
         if (rc == H263MI_OK && any_inter && !has_ref) rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS;          // gather.rs:149
         if (rc == H263MI_OK && any_inter && !same) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;           // (see the head of this section)
         if (rc == H263MI_OK && d_rgba && d_rgba[i] && rgba_capacity[i] < (size_t)w * h * 4) rc = H263MI_ERR_INVALID_ARGUMENT;
-        if (rc == H263MI_OK) rc = m->class_of(w, h, &target[i]);
+        if (rc == H263MI_OK) rc = m->class_of(w, h, target, &target[i]);
         if (rc != H263MI_OK) target[i] = -1;
         stream_rc[i] = rc;
     }
@@ -1628,6 +1656,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
     static const uint32_t kNoEvents[1] = {0};
     for (size_t k = 0; k < m->classes.size() && call_rc == H263MI_OK; k++) {
         h263mi_batch *b = m->classes[k].b;
+        if (!b) continue;                        // (a class that was given up: class_of)
         uint32_t members = 0;
         bool any_out = false;
         for (uint32_t i = 0; i < n; i++) {
@@ -1693,7 +1722,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
     // a class that is waiting to render its previous pictures and had nothing to decode in this call renders them now
     // (on a pipelined class the rendering rides in the NEXT launch of that class: without one it would wait for the sync)
     for (h263mi_mixed::SizeClass &c : m->classes)
-        if (!c.submitted && c.b->pending.valid) {
+        if (c.b && !c.submitted && c.b->pending.valid) {
             const int rc = c.b->flush_pending();
             if (rc != H263MI_OK && call_rc == H263MI_OK) call_rc = rc;
         }
@@ -1710,6 +1739,7 @@ int h263mi_mixed_sync(h263mi_mixed *m, int *stream_rc)
     int first_error = H263MI_OK;
     std::vector<int> rcs(m->n);
     for (size_t k = 0; k < m->classes.size(); k++) {
+        if (!m->classes[k].b) continue;
         const int rc = m->classes[k].b->sync(rcs.data());
         if (rc != H263MI_OK && first_error == H263MI_OK) first_error = rc;
         for (uint32_t i = 0; i < m->n; i++)

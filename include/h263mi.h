@@ -467,7 +467,8 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
 int h263mi_mixed_sync(h263mi_mixed *m, int *stream_rc);
 /* size of stream `stream`'s last picture (H263MI_ERR_NO_PICTURE and 0 x 0 when it has none) */
 int h263mi_mixed_stream_size(const h263mi_mixed *m, uint32_t stream, uint16_t *width, uint16_t *height);
-/* number of size classes (fixed-geometry batches) created so far */
+/* number of size classes (fixed-geometry batches) alive.  A class no stream belongs to any more is given up when the next
+ * class is made, so a stream that changes its size with every key frame does not make the set grow. */
 uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m);
 /* DecodedPicture::as_yuv of stream `stream`'s last picture: tightly packed planes to HOST memory */
 int h263mi_mixed_copy_yuv(h263mi_mixed *m, uint32_t stream, uint8_t *y, uint8_t *cb, uint8_t *cr);

@@ -437,6 +437,53 @@ def test_mixed_sizes_in_one_set(pipeline):
     m.close()
 
 
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_a_stream_that_keeps_changing_its_size_does_not_grow_the_set(pipeline):
+    """The dimensions come out of the bitstream (a Sorenson custom format carries 16-bit sizes): a stream that brings a key
+    frame of a new size every time must not leave a frame store behind for every size it ever had.  A class nobody belongs
+    to any more is given up when the next class is made; the pictures -- also the P picture decoded at each size, and the
+    RGBA of a picture whose class is given up right after it was rendered -- stay the oracle's."""
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    q, strength = 6, 5
+    sizes = [(176, 144), (352, 288), (96, 80), (640, 360), (176, 144), (320, 240), (96, 80), (128, 96)]
+    m = h263mi.MixedBatch(2, pipeline_post=pipeline)
+    rgba = [[h263mi.DeviceBuffer(640 * 360 * 4) for _ in range(2)] for _ in range(2 * len(sizes))]
+    refs, want = [None, None], []
+    fixed = (352, 288)                                           # stream 1 stays at CIF
+    call = 0
+    for k, size in enumerate(sizes):
+        for intra in (True, False):
+            datas = []
+            for s_, (w, h) in enumerate((size, fixed)):
+                first = intra and (s_ == 0 or k == 0)
+                if first:
+                    mbs, co = recgen.intra_picture(w, h, seed=97 * call + s_, max_level=60)
+                else:
+                    mbs, co = recgen.inter_picture(w, h, seed=97 * call + s_, mv_range=32, p_4v=0.2, p_intra=0.05, p_coded=0.4,
+                                                   quant=q, max_level=60)
+                mbs = make_codable(mbs, q, call + s_, 0 if first else 1)
+                datas.append(enc.encode_picture(w, h, 0 if first else 1, q, mbs, co, temporal_reference=call % 256))
+                rc, refs[s_] = orc.decode_picture(w, h, mbs, co, None if first else refs[s_])
+                assert rc == 0
+                want.append((call, s_, w, h, _rgba_want(refs[s_], strength, w)))
+            used, rcs, descs = m.decode_next_pictures(datas, n_threads=2, strength=strength, rgba=rgba[call])
+            assert rcs == [0, 0], "call %d: %s" % (call, rcs)
+            assert (descs[0].width, descs[0].height) == size
+            # stream 0's class, stream 1's class, and at most the one stream 0 has just left
+            assert m.size_classes() <= 3, "call %d: %d classes" % (call, m.size_classes())
+            call += 1
+    assert not any(m.sync())
+    assert m.stream_size(0) == sizes[-1] and m.stream_size(1) == fixed
+    for s_ in range(2):
+        assert_planes_equal(m.copy_yuv(s_), refs[s_], "stream %d at the end" % s_)
+    for c, s_, w, h, expect in want:
+        got = rgba[c][s_].download(w * h * 4)
+        assert np.array_equal(got, expect), "RGBA of call %d stream %d (%dx%d)" % (c, s_, w, h)
+    m.close()
+
+
 def test_overlap_mode_with_streams_that_have_drifted_apart():
     """H263MI_CFG_OVERLAP_POST (k_post on a second HIP stream) together with per-stream state words -- one stream
     sits calls out, so the streams' ping-pong positions differ and every wave reads its stream's word.  The words are now

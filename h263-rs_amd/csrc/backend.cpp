@@ -1506,9 +1506,21 @@ struct h263mi_mixed {
     std::vector<bits::ParserContext> parser_ctx;
     std::vector<bits::ParsedPicture> parsed;
     std::unique_ptr<WorkerPool> pool;
+    // What the frame stores of all classes together may take (0 = no limit).  A class holds two frames per stream of the SET,
+    // whatever the number of its members -- slot = stream index -- and the sizes come out of untrusted bitstreams: without a
+    // limit one hostile key frame of 16 384 x 16 384 in a set of 64 streams asks for 50 GB.
+    uint64_t limit_bytes = 0;
     ~h263mi_mixed()
     {
         for (SizeClass &c : classes) delete c.b;
+    }
+    uint64_t class_bytes(uint32_t w, uint32_t h) const { return 2ull * n * make_layout(w, h).frame_bytes; }
+    uint64_t store_bytes() const
+    {
+        uint64_t sum = 0;
+        for (const SizeClass &c : classes)
+            if (c.b) sum += class_bytes(c.w, c.h);
+        return sum;
     }
     WorkerPool &workers(unsigned want)
     {
@@ -1537,6 +1549,7 @@ struct h263mi_mixed {
             }
             if (slot < 0) slot = (int)k;
         }
+        if (limit_bytes && store_bytes() + class_bytes(w, h) > limit_bytes) return H263MI_ERR_OUT_OF_MEMORY;
         h263mi_batch *b = nullptr;
         RC_TRY(batch_create(n, w, h, &cfg, &b));
         // no stream of a new class has a picture: every slot starts inactive and without one
@@ -1572,6 +1585,12 @@ int h263mi_mixed_create(uint32_t n_streams, const h263mi_backend_cfg *cfg, h263m
     if (cfg) m->cfg = *cfg;
     m->cfg.device_id = dev;
     m->cfg.flags &= ~H263MI_CFG_OVERLAP_POST;     // (one HIP stream carries the classes' launches back to back)
+    {
+        // default limit: half of the device's memory
+        DeviceGuard g(dev);
+        size_t free_b = 0, total_b = 0;
+        if (g.ok && hipMemGetInfo(&free_b, &total_b) == hipSuccess) m->limit_bytes = total_b / 2;
+    }
     m->cls.assign(n_streams, -1);
     m->parser_ctx.assign(n_streams, bits::ParserContext());
     m->parsed.resize(n_streams);
@@ -1592,6 +1611,15 @@ int h263mi_mixed_stream_size(const h263mi_mixed *m, uint32_t stream, uint16_t *w
 }
 
 uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m) { return m ? m->live_classes() : 0; }
+
+int h263mi_mixed_set_memory_limit(h263mi_mixed *m, uint64_t bytes)
+{
+    if (!m) return H263MI_ERR_INVALID_ARGUMENT;
+    m->limit_bytes = bytes;
+    return H263MI_OK;
+}
+
+uint64_t h263mi_mixed_frame_store_bytes(const h263mi_mixed *m) { return m ? m->store_bytes() : 0; }
 
 int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options, const uint8_t *const *data, const size_t *len,
                                       size_t *consumed, uint32_t n_threads, int *stream_rc, uint8_t strength,

@@ -78,7 +78,8 @@ EXPORTS = [
     "h263mi_render_rgba_pinned", "h263mi_host_alloc", "h263mi_host_free", "h263mi_host_register", "h263mi_host_unregister",
     "h263mi_debug_fail_nth_hip_call",
     "h263mi_mixed_create", "h263mi_mixed_destroy", "h263mi_mixed_decode_next_pictures", "h263mi_mixed_sync",
-    "h263mi_mixed_stream_size", "h263mi_mixed_size_classes", "h263mi_mixed_copy_yuv", "h263mi_mixed_reset_stream",
+    "h263mi_mixed_stream_size", "h263mi_mixed_size_classes", "h263mi_mixed_set_memory_limit",
+    "h263mi_mixed_frame_store_bytes", "h263mi_mixed_copy_yuv", "h263mi_mixed_reset_stream",
 ]
 
 
@@ -173,6 +174,9 @@ def lib():
         L.h263mi_mixed_stream_size.argtypes = [vp, u32, C.POINTER(u16), C.POINTER(u16)]
         L.h263mi_mixed_size_classes.argtypes = [vp]
         L.h263mi_mixed_size_classes.restype = u32
+        L.h263mi_mixed_set_memory_limit.argtypes = [vp, C.c_uint64]
+        L.h263mi_mixed_frame_store_bytes.argtypes = [vp]
+        L.h263mi_mixed_frame_store_bytes.restype = C.c_uint64
         L.h263mi_mixed_copy_yuv.argtypes = [vp, u32, vp, vp, vp]
         L.h263mi_mixed_reset_stream.argtypes = [vp, u32]
         L.h263mi_batch_decode_next_pictures.argtypes = [vp, u32, vp, vp, vp, u32]
@@ -653,6 +657,13 @@ class MixedBatch:
 
     def size_classes(self):
         return lib().h263mi_mixed_size_classes(self._h)
+
+    def set_memory_limit(self, n_bytes):
+        """what the frame stores of all size classes together may take (0 = no limit; default: half of the device's memory)"""
+        _check(lib().h263mi_mixed_set_memory_limit(self._h, int(n_bytes)), "mixed_set_memory_limit")
+
+    def frame_store_bytes(self):
+        return int(lib().h263mi_mixed_frame_store_bytes(self._h))
 
     def copy_yuv(self, stream):
         w, h = self.stream_size(stream)

@@ -295,6 +295,10 @@ public:
     void reset_stream(uint32_t stream) { check(h263mi_mixed_reset_stream(m_, stream)); }
     // how many picture sizes the set has met so far (one fixed-geometry batch and one launch per call each)
     uint32_t size_classes() const { return h263mi_mixed_size_classes(m_); }
+    // device memory the frame stores of all sizes together may take (0 = no limit; default: half of the device's memory): a
+    // picture of a new size that would go beyond it is that stream's Error (H263MI_ERR_OUT_OF_MEMORY)
+    void set_memory_limit(uint64_t bytes) { check(h263mi_mixed_set_memory_limit(m_, bytes)); }
+    uint64_t frame_store_bytes() const { return h263mi_mixed_frame_store_bytes(m_); }
     h263mi_mixed *raw() { return m_; }
 
 private:

@@ -484,6 +484,46 @@ def test_a_stream_that_keeps_changing_its_size_does_not_grow_the_set(pipeline):
     m.close()
 
 
+def test_a_picture_size_beyond_the_memory_limit_is_refused_for_its_stream_only():
+    """A class holds two frames per stream of the set; the size comes out of the bitstream.  With a limit that leaves room for
+    the QCIF and CIF classes only, the stream that brings a 1080p key frame gets H263MI_ERR_OUT_OF_MEMORY and keeps what it
+    had; the others decode; with the limit raised the same key frame goes through."""
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    q = 6
+    n = 3
+    m = h263mi.MixedBatch(n)
+
+    def key_frame(w, h, seed):
+        mbs, co = recgen.intra_picture(w, h, seed=seed, max_level=60)
+        mbs = make_codable(mbs, q, seed, 0)
+        rc, ref = orc.decode_picture(w, h, mbs, co, None)
+        assert rc == 0
+        return enc.encode_picture(w, h, 0, q, mbs, co, temporal_reference=0), ref
+
+    small = [key_frame(176, 144, 1), key_frame(352, 288, 2), key_frame(176, 144, 3)]
+    used, rcs, _ = m.decode_next_pictures([d for d, _ in small])
+    assert rcs == [0, 0, 0] and not any(m.sync())
+    have = m.frame_store_bytes()
+    assert have >= 2 * n * (176 * 144 + 352 * 288) * 3 // 2
+    m.set_memory_limit(have + 1024 * 1024)                       # nothing like 2 x 3 frames of 1080p (19 MB)
+    big, big_ref = key_frame(1920, 1080, 4)
+    nxt, nxt_ref = key_frame(352, 288, 5)
+    used, rcs, _ = m.decode_next_pictures([big, nxt, None])
+    assert rcs == [h263mi.ERR_OUT_OF_MEMORY, 0, 0], rcs
+    assert not any(m.sync())
+    assert m.stream_size(0) == (176, 144) and m.size_classes() == 2 and m.frame_store_bytes() == have
+    assert_planes_equal(m.copy_yuv(0), small[0][1], "the refused stream keeps its picture")
+    assert_planes_equal(m.copy_yuv(1), nxt_ref, "the others advance")
+    m.set_memory_limit(0)
+    used, rcs, _ = m.decode_next_pictures([big, None, None])
+    assert rcs == [0, 0, 0] and not any(m.sync())
+    assert m.stream_size(0) == (1920, 1080)
+    assert_planes_equal(m.copy_yuv(0), big_ref, "the key frame with the limit lifted")
+    m.close()
+
+
 def test_overlap_mode_with_streams_that_have_drifted_apart():
     """H263MI_CFG_OVERLAP_POST (k_post on a second HIP stream) together with per-stream state words -- one stream
     sits calls out, so the streams' ping-pong positions differ and every wave reads its stream's word.  The words are now

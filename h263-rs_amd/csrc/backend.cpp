@@ -228,6 +228,8 @@ struct StreamDeal {
 uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
 uint32_t recon_tiles_y(const FrameLayout &L) { return (L.mbh + TILE_MBY - 1) / TILE_MBY; }
 uint32_t post_tiles_y(const FrameLayout &L) { return (post_strips_y(L.height) + POST_STRIPS - 1) / POST_STRIPS; }
+// what the parser asks right behind a picture header (bits::ParsedPicture::size_fits): can the frame store hold such a picture?
+bool picture_size_fits(uint32_t w, uint32_t h) { return layout_fits(w, h); }
 // tile geometry of k_post for the layout in a.L (post_kernel.inl: post_tile_columns)
 void set_post_tiles(PostArgs &a)
 {
@@ -1271,6 +1273,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
             if (!data[i] || !b->ss[i].active) return;            // no picture for this stream in this call
             bits::ParsedPicture &pic = b->parsed[i];
             pic.want_dense = false;                              // the coefficients travel as events
+            pic.size_fits = &picture_size_fits;
             pic.mbs_ext = g2.h_mbs + (size_t)i * per;
             pic.mbs_ext_cap = per;
             int rc = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
@@ -1640,6 +1643,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
             if (!data[i]) return;
             bits::ParsedPicture &pic = m->parsed[i];
             pic.want_dense = false;
+            pic.size_fits = &picture_size_fits;
             pic.mbs_ext = nullptr;               // (the class -- and with it the staging slot -- is known after the header)
             pic.mbs_ext_cap = 0;
             rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &m->parser_ctx[i], pic);
@@ -1968,6 +1972,7 @@ int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len,
     // serial half on the host (state.rs:143-427) ...
     bits::ParsedPicture &pic = s->parsed;                // (kept between calls: no allocation per picture)
     pic.want_dense = false;                              // the coefficients travel as events
+    pic.size_fits = &picture_size_fits;
     pic.mbs_ext = nullptr;
     pic.mbs_ext_cap = 0;
     if (s->b) {

@@ -776,6 +776,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     }
     if (!format.dimensions(hdr.width, hdr.height)) return H263MI_ERR_PICTURE_FORMAT_INVALID;
     if (!hdr.width || !hdr.height) return H263MI_ERR_PICTURE_FORMAT_INVALID;   // no picture to hold (back-end limit)
+    if (out.size_fits && !out.size_fits(hdr.width, hdr.height)) return H263MI_ERR_PICTURE_FORMAT_INVALID;   // (see ParsedPicture::size_fits)
 
     out.desc.width = hdr.width;
     out.desc.height = hdr.height;

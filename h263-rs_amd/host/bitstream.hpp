@@ -231,6 +231,11 @@ struct ParsedPicture {
     // the same coefficients as events, level << 16 | raster position, block k = [block_first_event[k], [k+1])
     WordBuffer block_first_event, events;
     bool want_dense = true;                // set to false before parsing to skip the dense blocks
+    // The caller's limit on the picture size (null = none), asked right behind the header -- before any of the arrays below is
+    // sized for the picture: a Sorenson custom format carries 16-bit dimensions out of an untrusted bitstream, and 65 535 x
+    // 65 535 is 16.7 M macroblocks (1.2 GB of records, vectors and block offsets) whether or not any data follows.  A picture
+    // beyond the limit is H263MI_ERR_PICTURE_FORMAT_INVALID.
+    bool (*size_fits)(uint32_t width, uint32_t height) = nullptr;
     // Test switch: read every field on its own, with its own end-of-data check -- the transcription of the reference's
     // parser that defines the behaviour -- instead of the windowed fast paths.  tests/test_parser_paths.py holds the two
     // against each other on valid, truncated and corrupted streams.

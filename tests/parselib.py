@@ -123,3 +123,14 @@ def parse_picture(data, options=1, cap_mbs=20000, cap_blocks=120000, use_context
     rc = lib().pt_parse_picture(a.ctypes.data, ln, options, C.byref(d), mbs.ctypes.data, cap_mbs, co.ctypes.data,
                                 cap_blocks, C.byref(n_mbs), C.byref(n_blocks), C.byref(bits), int(use_context))
     return rc, d, mbs[:n_mbs.value].copy(), co[:n_blocks.value].copy(), bits.value
+
+
+def parse_picture_limited(data, max_w, max_h, options=1):
+    """(rc, 32-bit words the parser's arrays were sized to) with ParsedPicture::size_fits = (w <= max_w and h <= max_h);
+    max_w = 0: no limit"""
+    a, ln = _bytes(data)
+    words = C.c_size_t()
+    f = lib().pt_parse_picture_limited
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
+    rc = f(a.ctypes.data, ln, options, max_w, max_h, C.byref(words))
+    return rc, words.value

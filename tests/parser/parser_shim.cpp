@@ -84,6 +84,21 @@ int pt_parse_picture(const uint8_t *data, size_t len, uint32_t options, h263mi_p
     return rc;
 }
 
+// parse_picture with the caller's limit on the picture size (ParsedPicture::size_fits): the return code, and how many 32-bit
+// words the parser's own arrays were sized to -- a picture beyond the limit must not have sized any of them for itself
+static uint32_t g_max_w = 0, g_max_h = 0;
+static bool pt_size_fits(uint32_t w, uint32_t h) { return w <= g_max_w && h <= g_max_h; }
+int pt_parse_picture_limited(const uint8_t *data, size_t len, uint32_t options, uint32_t max_w, uint32_t max_h, size_t *words)
+{
+    ParsedPicture p;
+    p.want_dense = false;
+    g_max_w = max_w; g_max_h = max_h;
+    p.size_fits = max_w ? &pt_size_fits : nullptr;
+    const int rc = parse_picture(data, len, options, nullptr, p);
+    *words = p.scratch.capacity() + p.block_first_event.capacity() + p.mbs.capacity() * (sizeof(h263mi_mb_record) / 4);
+    return rc;
+}
+
 // Both forms of the parser on the same bytes: the windowed fast paths against the field-by-field transcription
 // (ParsedPicture::field_by_field).  Returns 0 when every output agrees -- return code, bits consumed, records, dense
 // coefficients, events, block index, the context for the next picture -- else a positive number naming the first

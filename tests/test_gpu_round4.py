@@ -524,6 +524,37 @@ def test_a_picture_size_beyond_the_memory_limit_is_refused_for_its_stream_only()
     m.close()
 
 
+def test_a_hostile_picture_size_is_that_streams_format_error_everywhere():
+    """65 535 x 65 535 in a Sorenson header: refused right behind the header (the parser is given the back-end's size limit)
+    by the single state, by a batch (per stream) and by a mixed set (per stream); nobody else is disturbed."""
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    hostile = enc.encode_picture(65535, 65535, 0, 10, [], np.zeros((0, 64), np.int16))
+    mbs, co = recgen.intra_picture(176, 144, seed=5, max_level=60)
+    mbs = make_codable(mbs, 6, 5, 0)
+    good = enc.encode_picture(176, 144, 0, 6, mbs, co)
+    rc, ref = orc.decode_picture(176, 144, mbs, co, None)
+    st = h263mi.H263State()
+    st.decode_next_picture(good)
+    with pytest.raises(h263mi.H263Error) as e:
+        st.decode_next_picture(hostile)
+    assert e.value.code == h263mi.ERR_PICTURE_FORMAT_INVALID
+    assert_planes_equal(st.get_last_picture().as_yuv(), ref, "state unchanged")
+    b = h263mi.Batch(2, 176, 144)
+    used, rcs = b.decode_next_pictures_ex([good, hostile], n_threads=2)
+    assert rcs == [0, h263mi.ERR_PICTURE_FORMAT_INVALID]
+    b.sync()
+    assert_planes_equal(b.copy_yuv(0), ref, "batch stream 0")
+    b.close()
+    m = h263mi.MixedBatch(2)
+    used, rcs, _ = m.decode_next_pictures([hostile, good], n_threads=2)
+    assert rcs == [h263mi.ERR_PICTURE_FORMAT_INVALID, 0] and not any(m.sync())
+    assert m.size_classes() == 1 and m.stream_size(0) == (0, 0)
+    assert_planes_equal(m.copy_yuv(1), ref, "mixed stream 1")
+    m.close()
+
+
 def test_overlap_mode_with_streams_that_have_drifted_apart():
     """H263MI_CFG_OVERLAP_POST (k_post on a second HIP stream) together with per-stream state words -- one stream
     sits calls out, so the streams' ping-pong positions differ and every wave reads its stream's word.  The words are now

@@ -135,3 +135,18 @@ def test_ones_behind_the_last_macroblock_are_a_macroblock_too_many_in_both_forms
             assert diff == 0 and used, (name, len(tail), diff, rc)
             diff, rc = pl.compare_parser_paths(data + tail, options)
             assert diff == 0, (name, len(tail), diff, rc)
+
+
+def test_a_picture_beyond_the_callers_size_limit_is_refused_before_anything_is_sized_for_it():
+    """A Sorenson custom format carries 16-bit dimensions out of an untrusted bitstream.  The library hands the parser the
+    back-end's limit (ParsedPicture::size_fits); a header of 65 535 x 65 535 -- 16.7 M macroblocks -- is refused right behind
+    the header, with none of the parser's arrays sized for it; without a limit the same header sizes them (and the picture
+    simply ends where the data ends, state.rs:411)."""
+    import h263mi
+    header_only = enc.encode_picture(65535, 65535, 0, 10, [], np.zeros((0, 64), np.int16))
+    rc, words = pl.parse_picture_limited(header_only, 4096, 4096)
+    assert rc == h263mi.ERR_PICTURE_FORMAT_INVALID and words < 1024
+    rc, words = pl.parse_picture_limited(enc.encode_picture(2048, 1024, 0, 10, [], np.zeros((0, 64), np.int16)), 4096, 4096)
+    assert rc == 0 and words >= 128 * 64 * 4                     # inside the limit: parsed (an empty picture), arrays sized
+    rc, words = pl.parse_picture_limited(enc.encode_picture(2048, 1024, 0, 10, [], np.zeros((0, 64), np.int16)), 0, 0)
+    assert rc == 0 and words >= 128 * 64 * 4                     # no limit given: as before

@@ -159,7 +159,7 @@ class Workload:
         # The transport is chosen per picture: events pay off for sparse blocks (a P picture's 4 LEVELs per block); a
         # picture that averages more than 8 events per coded block (the GOP's I picture) stays dense -- rebuilding its
         # blocks from events takes the reconstruction waves eight trips per round.
-        if int(first[-1]) > 8 * max(blocks, 1):
+        if int(first[-1]) > 8 * max(blocks, 1) and not os.environ.get("H263MI_BENCH_EVENTS_ALWAYS"):   # (the switch: probes only)
             return dict(first=None, ev=None, n_events=int(first[-1]))
         d_first = h263mi.DeviceBuffer(first.nbytes, device_id)
         d_first.upload(first)

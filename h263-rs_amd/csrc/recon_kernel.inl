@@ -781,6 +781,17 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
         if (told) *bad_events |= bad;
         wave_fence();                                           // zeroed before the first LEVEL lands
 #if defined(__HIP_DEVICE_COMPILE__)
+        // Blocks with more than 8 events (intra pictures, mostly) take all their trips at once: the (up to) eight reads are in
+        // flight together instead of one memory round trip after the other -- a block of 64 events was eight of them.
+        while (__ballot(at + 8u < end) != 0) {
+            uint32_t ev[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) ev[j] = at + 8u * (uint32_t)j < end ? a.events[at + 8u * (uint32_t)j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (at + 8u * (uint32_t)j < end) dense[slot * 64 + (int)(ev[j] & 63u)] = (int16_t)(ev[j] >> 16);
+            at += 64u;
+        }
         while (__ballot(at < end) != 0) {
 #else
         while (at < end) {

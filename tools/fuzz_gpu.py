@@ -105,6 +105,91 @@ def fuzz_batch(rng, w, h, seed, n_pic, n_px):
     return n_pic, n_px
 
 
+def fuzz_mixed(rng, seed, n_pic, n_px):
+    """A set of streams of different (and changing) picture sizes behind one call (h263mi_mixed): per call every stream
+    does one of -- nothing, a P picture, a key frame of its size, a key frame of ANOTHER size (the stream moves), a P picture
+    of another size (refused: PICTURE_FORMAT_INVALID, state kept), a reset -- and every plane and every RGBA picture is the
+    oracle's; the number of size classes stays within two per stream (the one it is in and the one it left)."""
+    n = int(rng.integers(2, 8))
+    pipeline = bool(rng.integers(0, 2))
+    strength = int(rng.integers(0, 13))
+    palette = [(176, 144), (352, 288), (96, 80), (128, 96), (int(rng.integers(17, 200)), int(rng.integers(17, 150))),
+               (4 * int(rng.integers(5, 60)), 4 * int(rng.integers(5, 40)))]
+    m = h263mi.MixedBatch(n, pipeline_post=pipeline)
+    refs, size = [None] * n, [None] * n
+    calls = int(rng.integers(3, 8))
+    q = int(rng.integers(2, 20))
+    rgba = [[h263mi.DeviceBuffer(max(w * h for w, h in palette) * 4) for _ in range(n)] for _ in range(calls)]
+    want = []
+    what = (n, pipeline, strength, seed)
+    for c in range(calls):
+        datas, expect = [], []
+        for s_ in range(n):
+            act = "key" if size[s_] is None and rng.random() < 0.8 else str(rng.choice(["idle", "p", "p", "p", "key", "move", "badp", "reset"]))
+            if act == "reset":
+                m.reset_stream(s_)
+                refs[s_], size[s_] = None, None
+                act = "idle"
+            if act == "idle":
+                datas.append(None)
+                expect.append(0)
+                continue
+            wh = size[s_] if act in ("p", "key") and size[s_] is not None else palette[int(rng.integers(0, len(palette)))]
+            if act == "badp" and (size[s_] is None or wh == size[s_]):
+                act = "p" if size[s_] is not None else "key"
+                wh = size[s_] if size[s_] is not None else wh
+            sd = int(rng.integers(0, 1 << 30))
+            intra = act in ("key", "move")
+            if intra:
+                mbs, co = recgen.intra_picture(wh[0], wh[1], seed=sd, max_level=int(rng.choice([40, 127, 1023])))
+            else:
+                mbs, co = recgen.inter_picture(wh[0], wh[1], seed=sd, mv_range=32, p_4v=float(rng.choice([0.0, 0.3])), p_intra=0.05,
+                                               p_coded=float(rng.choice([0.1, 0.5])), quant=q, max_level=int(rng.choice([60, 1023])))
+            mbs = make_codable(mbs, q, sd, 0 if intra else 1)
+            datas.append(enc.encode_picture(wh[0], wh[1], 0 if intra else 1, q, mbs, co, temporal_reference=c))
+            if not intra and refs[s_] is None:
+                expect.append(h263mi.ERR_UNCODED_IFRAME_BLOCKS)
+            elif not intra and wh != size[s_]:
+                expect.append(h263mi.ERR_PICTURE_FORMAT_INVALID)
+            else:
+                rc, refs[s_] = orc.decode_picture(wh[0], wh[1], mbs, co, None if intra else refs[s_])
+                assert rc == 0
+                size[s_] = wh
+                expect.append(0)
+                cw = (wh[0] + 1) // 2
+                planes = refs[s_] if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(refs[s_], (wh[0], cw, cw)))
+                want.append((c, s_, wh, orc.yuv420_to_rgba(*planes, wh[0])))
+                n_pic += 1
+                n_px += wh[0] * wh[1]
+        used, rcs, descs = m.decode_next_pictures(datas, n_threads=int(rng.integers(1, 4)), strength=strength, rgba=rgba[c])
+        if list(rcs) != expect:
+            raise FuzzMismatch("mixed set: call %d return codes %s, expected %s: %r" % (c, list(rcs), expect, what))
+        if m.size_classes() > 2 * n:
+            raise FuzzMismatch("mixed set: %d size classes for %d streams: %r" % (m.size_classes(), n, what))
+        if rng.random() < 0.5 and any(m.sync()):
+            raise FuzzMismatch("mixed set: device verdict: %r" % (what,))
+    if any(m.sync()):
+        raise FuzzMismatch("mixed set: device verdict at the end: %r" % (what,))
+    for s_ in range(n):
+        if refs[s_] is None:
+            if m.stream_size(s_) != (0, 0):
+                raise FuzzMismatch("mixed set: stream %d should have no picture: %r" % (s_, what))
+            continue
+        if m.stream_size(s_) != size[s_]:
+            raise FuzzMismatch("mixed set: stream %d size %s, expected %s: %r" % (s_, m.stream_size(s_), size[s_], what))
+        for g, e, name in zip(m.copy_yuv(s_), refs[s_], "Y Cb Cr".split()):
+            if not (np.asarray(g) == e.ravel()).all():
+                raise FuzzMismatch("mixed set: stream %d %s: %r" % (s_, name, what))
+    for c, s_, wh, expect_rgba in want:
+        if not (rgba[c][s_].download(wh[0] * wh[1] * 4) == expect_rgba.ravel()).all():
+            raise FuzzMismatch("mixed set: RGBA of call %d stream %d %s: %r" % (c, s_, wh, what))
+    m.close()
+    for row in rgba:
+        for d in row:
+            d.free()
+    return n_pic, n_px
+
+
 def run(budget=60.0, seed=1, verbose=True):
     """random pictures for `budget` seconds; returns (pictures, pixels); raises FuzzMismatch on the first difference"""
     rng = np.random.default_rng(seed)
@@ -122,6 +207,9 @@ def run(budget=60.0, seed=1, verbose=True):
                             rng.integers(260, 800), 4 * rng.integers(65, 200)]))
         h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288,
                             rng.integers(64, 420), 4 * rng.integers(16, 100)]))
+        if rng.random() < 0.08:
+            n_pic, n_px = fuzz_mixed(rng, seed, n_pic, n_px)
+            continue
         if rng.random() < 0.2:
             # a BATCH of streams in lock step (h263mi_batch_decode / _decode_events), plain or frame-pipelined: the launch
             # that the bench times, at random sizes, stream counts, transports and filter strengths; RGBA of every

@@ -15,7 +15,10 @@
  *                              PARITY UNPINNED -- the reference holds no test for
  *                              these functions and its Rust toolchain is absent here;
  *                              cross-checked against an independent numpy restatement
- *                              (oracle/np_restatement.py) and hand-derivable identities.
+ *                              (oracle/np_restatement.py), an FPU-free soft-float model, hand-
+ *                              derivable identities, and -- from the other side -- ITU-T H.263
+ *                              itself (tests/test_oracle_vs_standard.py: the IDCT accuracy
+ *                              specification of Annex A, the prediction formulas of 6.1.2).
  */
 #ifndef H263_ORACLE_H
 #define H263_ORACLE_H

@@ -228,6 +228,9 @@ struct StreamDeal {
 uint32_t recon_tiles_x(const FrameLayout &L) { return (L.mbw + TILE_MBX - 1) / TILE_MBX; }
 uint32_t recon_tiles_y(const FrameLayout &L) { return (L.mbh + TILE_MBY - 1) / TILE_MBY; }
 uint32_t post_tiles_y(const FrameLayout &L) { return (post_strips_y(L.height) + POST_STRIPS - 1) / POST_STRIPS; }
+// Event indices are 32-bit on the device, 0xffffffff stands for "the caller did not say how many" (ReconArgs::n_events), and a
+// lane looks up to 64 words past its first event before it compares with the block's end: the count stays clear of the top.
+constexpr uint64_t kMaxEventWords = 0xffffff00ull;
 // what the parser asks right behind a picture header (bits::ParsedPicture::size_fits): can the frame store hold such a picture?
 bool picture_size_fits(uint32_t w, uint32_t h) { return layout_fits(w, h); }
 // tile geometry of k_post for the layout in a.L (post_kernel.inl: post_tile_columns)
@@ -1027,7 +1030,7 @@ int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263
                                uint8_t *d_deblocked)
 {
     if (!b || !d_mbs || !d_block_first_event || !d_events || picture_type > H263MI_PICTURE_RESERVED || strength > 12 ||
-        n_events > 0xffffffffull)
+        n_events > kMaxEventWords)
         return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     b->coeff_checked = coeff_pool_blocks != 0;
@@ -1075,7 +1078,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         blocks += n_coeff_blocks[i];
         if (sparse) n_ev += n_events[i];
     }
-    if (blocks > 0xffffffffu / 8u || n_ev > 0xffffffffu) return H263MI_ERR_INVALID_ARGUMENT;
+    if (blocks > 0xffffffffu / 8u || n_ev > kMaxEventWords) return H263MI_ERR_INVALID_ARGUMENT;
     DeviceGuard g(b->device);
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
     h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];

@@ -326,7 +326,8 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
  * n_events (ABI 4): the number of words d_events holds, or 0 = not told.  The device arrays are the caller's and nobody
  * has validated them; when n_events is given, a block whose bounds are not ascending or reach beyond it is NOT read and
  * the stream's picture is rejected at the next sync (H263MI_ERR_INVALID_ARGUMENT, like a coded block outside the pool).
- * With 0 the caller vouches for its arrays: the bounds are used as they are and the waves spend nothing on them. */
+ * With 0 the caller vouches for its arrays: the bounds are used as they are and the waves spend nothing on them.
+ * At most 0xffffff00 words (event indices are 32-bit on the device; more is H263MI_ERR_INVALID_ARGUMENT). */
 int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
                                const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
                                uint64_t coeff_pool_blocks, uint64_t n_events, uint8_t strength, uint8_t *d_rgba,

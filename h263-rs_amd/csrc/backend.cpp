@@ -271,6 +271,7 @@ struct h263mi_batch {
     uint8_t **h_ptrs = nullptr, **d_ptrs = nullptr;
     hipEvent_t ptrs_copied[kPtrSlots] = {nullptr, nullptr, nullptr, nullptr};
     unsigned ptrs_slot = 0;
+    bool ptrs_ready = false;            // the ring above exists completely (push_rgba_ptrs makes it on first use)
     uint32_t n = 0;
     FrameLayout L{};
     uint8_t *frames[2] = {nullptr, nullptr};   // ping-pong frame sets, n * frame_bytes each
@@ -404,13 +405,37 @@ struct h263mi_batch {
         return H263MI_OK;
     }
 
+    int make_ptr_ring()
+    {
+        HIP_TRY(hipHostMalloc((void **)&h_ptrs, (size_t)n * kPtrSlots * sizeof(uint8_t *), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&d_ptrs, (size_t)n * kPtrSlots * sizeof(uint8_t *)));
+        for (hipEvent_t &e : ptrs_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return H263MI_OK;
+    }
+    void release_ptr_ring()
+    {
+        if (d_ptrs) (void)hipFree(d_ptrs);
+        if (h_ptrs) (void)hipHostFree(h_ptrs);
+        d_ptrs = nullptr;
+        h_ptrs = nullptr;
+        for (hipEvent_t &e : ptrs_copied) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        ptrs_ready = false;
+    }
     // hand the post-processing one output pointer per stream (host array of n DEVICE pointers): next ring slot + its copy
     int push_rgba_ptrs(uint8_t *const *host_ptrs, uint8_t *const **d_out, hipStream_t on)
     {
-        if (!h_ptrs) {
-            HIP_TRY(hipHostMalloc((void **)&h_ptrs, (size_t)n * kPtrSlots * sizeof(uint8_t *), hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&d_ptrs, (size_t)n * kPtrSlots * sizeof(uint8_t *)));
-            for (hipEvent_t &e : ptrs_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!ptrs_ready) {
+            // all or nothing: a failure half-way (the host block is there, the device block or an event is not) frees what
+            // was made, so that the next call starts over instead of synchronising on an event that does not exist
+            const int rc = make_ptr_ring();
+            if (rc != H263MI_OK) {
+                release_ptr_ring();
+                return rc;
+            }
+            ptrs_ready = true;
         }
         const unsigned slot = ptrs_slot++ % kPtrSlots;
         HIP_TRY(hipEventSynchronize(ptrs_copied[slot]));
@@ -471,10 +496,7 @@ struct h263mi_batch {
         if (h_status) (void)hipHostFree(h_status);
         if (d_state) (void)hipFree(d_state);
         if (h_state) (void)hipHostFree(h_state);
-        if (d_ptrs) (void)hipFree(d_ptrs);
-        if (h_ptrs) (void)hipHostFree(h_ptrs);
-        for (hipEvent_t e : ptrs_copied)
-            if (e) (void)hipEventDestroy(e);
+        release_ptr_ring();
         for (hipEvent_t e : state_copied)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -1689,7 +1711,9 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
     std::vector<uint8_t> types(n), was_active(n);
     std::vector<uint8_t *> out_ptrs(n);
     static const uint32_t kNoEvents[1] = {0};
-    for (size_t k = 0; k < m->classes.size() && call_rc == H263MI_OK; k++) {
+    // (a class whose RENDERING fails does not stop the others: every class that has pictures is decoded, and the first
+    // rendering error is what the call returns at the end -- no stream is left with H263MI_OK and no decoded picture)
+    for (size_t k = 0; k < m->classes.size(); k++) {
         h263mi_batch *b = m->classes[k].b;
         if (!b) continue;                        // (a class that was given up: class_of)
         uint32_t members = 0;
@@ -1745,7 +1769,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
                 int render_rc = H263MI_OK;
                 if (deferred) render_rc = b->note_pending(strength, nullptr, nullptr, out_ptrs.data());
                 else if (any_out) render_rc = b->render(strength, nullptr, nullptr, /*only_active=*/true, out_ptrs.data());
-                if (render_rc != H263MI_OK) call_rc = render_rc;
+                if (render_rc != H263MI_OK && call_rc == H263MI_OK) call_rc = render_rc;
             } else {
                 // the class's launch did not happen: its members keep their state and get the error
                 for (uint32_t i = 0; i < n; i++)

@@ -174,7 +174,11 @@ __device__ __forceinline__ void recon_round_rows(const ReconArgs &a, ReconWave &
     // non-zero LEVEL in columns 6..7 of every lane's coefficient row means eight active blocks (an empty slot holds zeros)
     // that all have something beyond their first column in every row: eight Full blocks, eight columns, eight rows
     // (rle.rs:138-149).  They take the instantiation without any of the general form's bookkeeping.
-    rs.dense = __ballot(rs.ri.w[3] != 0) == ~0ull;
+    // A LEVEL outside [-512, 511] anywhere in the round (one ballot): the reference's i16 dequantiser may have overflowed,
+    // and the round takes the wrapping form of the row pass (recon_kernel.inl: dequant_pair_wrap) -- hostile or broken
+    // streams only, but bit for bit what a release build of the reference makes of them.
+    const bool wide = __ballot(rowin_wide_bits(rs.ri) != 0) != 0;
+    rs.dense = !wide && __ballot(rs.ri.w[3] != 0) == ~0ull;
     if (rs.dense) {
         wave_fence();                       // the column pass of the previous round has read tbuf
         recon_phase_idct_rows<true>(s, rs.ri, ln, 8, ~0ull);
@@ -189,7 +193,8 @@ __device__ __forceinline__ void recon_round_rows(const ReconArgs &a, ReconWave &
     rs.rows_any = __ballot(rc.any);
     rs.cols_any = __ballot(rc.beyond_first);                          // bit slot*8 + row
     wave_fence();                           // the column pass of the previous round has read tbuf
-    recon_phase_idct_rows(s, rs.ri, ln, cols_from_mask(wm), rs.cols_any);
+    if (wide) recon_phase_idct_rows<false, true>(s, rs.ri, ln, cols_from_mask(wm), rs.cols_any);
+    else recon_phase_idct_rows(s, rs.ri, ln, cols_from_mask(wm), rs.cols_any);
     uint32_t rows_mask = (uint32_t)rs.rows_any | (uint32_t)(rs.rows_any >> 32);
     rows_mask |= rows_mask >> 16;
     rows_mask |= rows_mask >> 8;

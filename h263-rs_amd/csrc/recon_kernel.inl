@@ -106,6 +106,10 @@ H263_HD bool     desc_intra(uint32_t d1) { return (d1 >> 19) & 1u; }
 // (bits 20 and up: where the block's 8x8 pixels start in the reconstruction strip, in units of 8 bytes -- worked out once per
 // task in the mark phase; rounds 1-3 carried the task number and every lane of every round derived the origin from it)
 H263_HD int      desc_pix_origin(uint32_t d1) { return (int)((d1 >> 20) << 3); }
+// (recon_phase_mark builds that field with literal shifts: a 128-byte strip row, the chroma rows behind 16 luma rows, and
+// twelve bits for origin / 8)
+static_assert(PIX_STRIDE == 128 && PIX_CHROMA == 16 * PIX_STRIDE && (PIX_CHROMA / 8 + 15) < 4096,
+              "the strip geometry recon_phase_mark's descriptor field (org8) is written for");
 
 // Wave-wide bit masks.  On the device they come out of ballots and live in scalar registers; the CPU logic checker
 // (tests/sim) runs the lanes one after the other and ORs the lanes' bits together.
@@ -370,8 +374,12 @@ H263_HD int rows_from_mask(uint32_t row_mask)       // bit r: some block has a n
 // multiply-add, the clamp to 12 bits IS the saturation to 16 bits -- a value beyond it lands on 32767 or -32768, and
 // with the four low bits cleared those are 16 * 2047 and 16 * -2048 (every other result is a multiple of 16 already).
 // One multiply-add and one AND instead of a multiply-add and two clamps; the row pass takes the factor out again
-// through its table (kBasisSixteenth).  The reference's i16 product overflows for 11-bit LEVELs at large quantisers; a
-// saturated value lands on the same side of the clamp.
+// through its table (kBasisSixteenth).
+// VALID ONLY WHERE THE REFERENCE'S i16 ARITHMETIC DOES NOT OVERFLOW: rle.rs:130-133 multiplies in i16, and a release build
+// (what Ruffle ships) WRAPS where q * (2|L| + 1) exceeds 32767 -- reachable with Sorenson's 11-bit escape LEVELs from q = 16
+// up (parser/block.rs:694-708) -- so the wrapped product, not the mathematical one, is what it clamps.  No |L| <= 511
+// overflows at any quantiser (31 * 1023 = 31713); a round that holds a wider LEVEL (rowin_wide_bits, one ballot) takes
+// dequant_pair_wrap below instead.
 // `two_q2`, `qmp2`: 2q and q - parity in both halves of a dword (2q <= 62, q - parity <= 31: times 16 they fit 10 bits).
 constexpr float DEQUANT_SCALE = 16.0f;
 H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qmp2)
@@ -395,6 +403,39 @@ H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qm
         const int two_q = (int)(two_q2 & 0xffffu), qmp = (int)(int16_t)(qmp2 & 0xffffu);
         const int sg = level > 0 ? 1 : (level < 0 ? -1 : 0);
         const int v = clampi(16 * (level * two_q + sg * qmp), -32768, 32767) & ~15;
+        out |= ((uint32_t)v & 0xffffu) << (16 * h);
+    }
+    return out;
+#endif
+}
+
+// rle.rs:130-133 exactly as a release build of the reference executes it, for ANY int16 LEVEL: every step is an i16 that
+// wraps.  sign(L) * (q * (2|L| + 1) + parity) = L * 2q + sign(L) * (q + parity) modulo 2^16 (|L| itself wraps for -32768, and
+// so does this form), then the clamp to [-2048, 2047]: a multiply-add WITHOUT saturation, a max and a min.  Returns the
+// value itself (not 16 x): the row pass of such a round uses the unscaled table.  Examples: q = 31, L = -1024: 31 * 2049 =
+// 63519 = -2017 (mod 2^16), times -1 -> +2017; q = 31, L = 529: 32829 = -32707 -> -2048 (where the mathematical product
+// would clamp to +2047).  Only rounds that hold a LEVEL outside [-512, 511] come here (rowin_wide_bits).
+H263_DEV uint32_t dequant_pair_wrap(uint32_t levels, uint32_t two_q2, uint32_t qmp2)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t sg, t, v;
+    asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]" : "=&v"(sg) : "v"(levels));   // -1, 0 or +1
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2));
+#if defined(H263MI_MUTATE_DEQUANT_WRAP)
+    // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the multiply-add saturates, i.e. the mathematical
+    // product is clamped where the reference clamps the wrapped one.  The wide-LEVEL test must notice.
+    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
+#else
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
+#endif
+    return pk_min_i16(pk_max_i16(v, 0xf800f800u), 0x07ff07ffu);
+#else
+    uint32_t out = 0;
+    for (int h = 0; h < 2; h++) {
+        const int level = (int)(int16_t)(levels >> (16 * h));
+        const int two_q = (int)(two_q2 & 0xffffu), qmp = (int)(int16_t)(qmp2 & 0xffffu);
+        const int sg = level > 0 ? 1 : (level < 0 ? -1 : 0);
+        const int v = clampi((int)(int16_t)(uint16_t)((uint32_t)(level * two_q + sg * qmp) & 0xffffu), -2048, 2047);
         out |= ((uint32_t)v & 0xffffu) << (16 * h);
     }
     return out;
@@ -855,6 +896,26 @@ H263_DEV uint32_t rowin_word_mask(const RowIn &ri)
     return (ri.w[1] ? 2u : 0u) | (ri.w[2] ? 4u : 0u) | (ri.w[3] ? 8u : 0u);
 }
 
+// Non-zero when some LEVEL of the lane's coefficient row lies outside [-512, 511] -- bits 15..9 of a half are not all
+// equal: bit k of w ^ (w + w) is L[k] ^ L[k - 1] (the bit the low half's shift pushes into the high half lands on bit 16,
+// outside the mask).  Only such a LEVEL can overflow the reference's i16 product (dequant_pair_i16); the round then
+// dequantises with dequant_pair_wrap.  Eight adds / xors, three ors and one and per row (the 2-cycle class).
+H263_DEV uint32_t rowin_wide_bits(const RowIn &ri)
+{
+    uint32_t t = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t twice;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("v_add_u32 %0, %1, %1" : "=v"(twice) : "v"(ri.w[j]));       // (written as w << 1 it becomes the 4-cycle v_lshlrev)
+#else
+        twice = ri.w[j] + ri.w[j];
+#endif
+        t |= ri.w[j] ^ twice;
+    }
+    return t & 0xfc00fc00u;
+}
+
 // What a lane's coefficient row contributes to the classification of its block (rle.rs:138-149): a non-zero value
 // with y > 0 breaks "horiz", one with x > 0 breaks "vert".  A LEVEL is non-zero exactly when its dequantised value
 // is (|v| >= 3q - 1), so this is decided on the raw words -- before the row pass, which needs to know the class.
@@ -883,9 +944,14 @@ H263_DEV RowClass recon_row_class(const RowIn &ri, int lane)
 // non-zero LEVEL in its last pair (kernels.hip: recon_round_rows decides it with one ballot).  Nothing of what the general
 // form spends on being general is left: no activity mask, no class, no column count -- dequantise 4 pairs, 8 terms, store.
 // The arithmetic is the general form's with n_cols = 8 and no first-column-only block: bit for bit the same results.
-template <bool DENSE = false>
+// WIDE (round 5): some LEVEL of the round lies outside [-512, 511] (rowin_wide_bits): the dequantiser is the wrapping
+// one (dequant_pair_wrap: the reference's i16 arithmetic as a release build executes it), the coefficients are not scaled
+// and the table is the basis itself.  Where nothing overflows both forms give the same bits (powers of two commute with
+// every rounding on the way), so WHICH rounds take this form is a matter of speed only.
+template <bool DENSE = false, bool WIDE = false>
 H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int n_cols, uint64_t cols_any)
 {
+    static_assert(!(DENSE && WIDE), "a wide round takes the general form");
     if (!DENSE && !ri.active) return;
     if (DENSE) n_cols = 8;
     const int slot = lane >> 3, r = lane & 7;
@@ -900,16 +966,18 @@ H263_DEV void recon_phase_idct_rows(ReconWave &s, const RowIn &ri, int lane, int
     for (int j = 0; j < 4; j++) {
         C[2 * j] = C[2 * j + 1] = 0.0f;
         if (2 * j < n_cols) {                               // uniform
-            const uint32_t v = dequant_pair_i16(ri.w[j], two_q2, qmp2);
+            const uint32_t v = WIDE ? dequant_pair_wrap(ri.w[j], two_q2, qmp2) : dequant_pair_i16(ri.w[j], two_q2, qmp2);
             C[2 * j] = (float)(int)(int16_t)(v & 0xffffu);
             C[2 * j + 1] = (float)((int)v >> 16);
         }
     }
-    if (use_dc) C[0] = (float)(int)(desc_level(ri.d1) * (uint32_t)DEQUANT_SCALE);     // (at most 2032 * 16)
+    if (use_dc) C[0] = (float)(int)(desc_level(ri.d1) * (WIDE ? 1u : (uint32_t)DEQUANT_SCALE));     // (at most 2032 * 16)
 
     // idct_1d over the coefficient row (idct.rs:52-65); C holds 16 x the coefficients, the table 1/16 of the basis
+    // (WIDE: the coefficients and the basis as they are)
     f32x2 T[4];
-    idct_1d_pairs(basis_table_sixteenth(), C, T, n_cols, first_column_only, 1.0f / DEQUANT_SCALE);
+    if (WIDE) idct_1d_pairs(basis_table(), C, T, n_cols, first_column_only, 1.0f);
+    else idct_1d_pairs(basis_table_sixteenth(), C, T, n_cols, first_column_only, 1.0f / DEQUANT_SCALE);
     float4_store(&s.tbuf[slot * TBUF_STRIDE + tbuf_row_offset(r)], T[0], T[1]);
     float4_store(&s.tbuf[slot * TBUF_STRIDE + tbuf_row_offset(r) + 4], T[2], T[3]);
 }

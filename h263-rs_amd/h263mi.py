@@ -494,8 +494,11 @@ class Batch:
 
     def decode_events(self, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base=None, coeff_pool_blocks=0,
                       strength=0, d_rgba=None, d_deblocked=None, n_events=0):
-        """h263mi_batch_decode_events: decode with the coefficients as sparse events in device memory (n_events: words in
-        d_events, 0 = not told: then the device only checks that a block's bounds ascend)"""
+        """h263mi_batch_decode_events: decode with the coefficients as sparse events in device memory.  n_events: words in
+        d_events.  Given it, a block whose bounds do not ascend or reach beyond it is not read and its picture is rejected.
+        0 = not told: the caller VOUCHES for d_block_first_event / d_events and the device checks NOTHING (include/h263mi.h)
+        -- unvalidated arrays can then make a wave read up to 64 words beyond a block's first event.  Pass the real count
+        unless the arrays come from a source that is valid by construction."""
         _check(lib().h263mi_batch_decode_events(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
                                                 coeff_pool_blocks, n_events, strength, d_rgba, d_deblocked), "batch_decode_events")
 
@@ -624,9 +627,11 @@ class MixedBatch:
         except Exception:
             pass
 
-    def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, strength=0, rgba=None):
+    def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, strength=0, rgba=None,
+                             raise_on_error=True):
         """data_list: bytes or None per stream; rgba: DeviceBuffer or None per stream (or None: no rendering).
-        Returns (bytes consumed, error codes, picture headers) per stream."""
+        Returns (bytes consumed, error codes, picture headers) per stream; with raise_on_error=False a call-level error
+        does not raise and comes back as a fourth element (the per-stream results are valid either way)."""
         assert len(data_list) == self.n
         empty = np.zeros(1, np.uint8)
         keep = [(np.frombuffer(bytes(d), dtype=np.uint8) if len(d) else empty) if d is not None else None for d in data_list]
@@ -639,8 +644,10 @@ class MixedBatch:
         if rgba is not None:
             ptrs = (C.c_void_p * self.n)(*[(r.ptr.value if hasattr(r.ptr, "value") else r.ptr) if r is not None else None for r in rgba])
             caps = (C.c_size_t * self.n)(*[r.nbytes if r is not None else 0 for r in rgba])
-        _check(lib().h263mi_mixed_decode_next_pictures(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength, ptrs, caps,
-                                                       descs), "mixed_decode_next_pictures")
+        rc = lib().h263mi_mixed_decode_next_pictures(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength, ptrs, caps, descs)
+        if not raise_on_error:
+            return list(used), list(rcs), list(descs), rc
+        _check(rc, "mixed_decode_next_pictures")
         return list(used), list(rcs), list(descs)
 
     def sync(self):

@@ -455,7 +455,11 @@ int h263mi_batch_timing_end(h263mi_batch *b, h263mi_kernel_times *out);
  *   d_rgba[s]          (d_rgba may be NULL: no rendering) DEVICE buffer of rgba_capacity[s] >= w*h*4 bytes of the picture
  *                      being decoded, or NULL for that stream: deblock(strength) + BT.601 of the picture, tightly packed;
  *   descs[s]           (may be NULL) receives the header fields of the picture stream s decoded, its size included.
- * Returns H263MI_OK when the call itself went through (look at stream_rc), else a back-end error.
+ * Returns H263MI_OK when the call itself went through (look at stream_rc), else a back-end error.  A back-end error of
+ * the RENDERING of one class (deblock + BT.601 into d_rgba) does not stop the call: every class that has pictures is still
+ * decoded -- stream_rc[s] == H263MI_OK always means "stream s decoded its picture and advanced", consumed[s] says so too --
+ * and the first such error is returned at the end; the contents of d_rgba of that call are then unspecified, the pictures
+ * themselves are intact (h263mi_mixed_copy_yuv, the next call's prediction).
  */
 typedef struct h263mi_mixed h263mi_mixed;
 int h263mi_mixed_create(uint32_t n_streams, const h263mi_backend_cfg *cfg, h263mi_mixed **out);

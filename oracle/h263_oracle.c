@@ -23,6 +23,13 @@ static inline ptrdiff_t clamp_pd(ptrdiff_t v, ptrdiff_t lo, ptrdiff_t hi)
 
 static inline int clamp_i(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* i16 arithmetic of a Rust release build: the result modulo 2^16, reinterpreted as signed */
+static inline int16_t wrap_i16(int v)
+{
+    const uint16_t u = (uint16_t)((unsigned)v & 0xffffu);
+    return (int16_t)(u >= 0x8000u ? (int)u - 0x10000 : (int)u);
+}
+
 /* Rust `f32 as i16`: truncate toward zero, saturate, NaN -> 0. */
 static inline int16_t f32_as_i16(float f)
 {
@@ -131,12 +138,18 @@ void orc_inverse_rle(const orc_block *eb, orc_dct_block *levels,
         zz += eb->run[t];
         if (zz >= 64) return;                  /* rle.rs:125-127: block left as it was */
         uint8_t zx = DEZIGZAG[zz][0], zy = DEZIGZAG[zz][1];
-        int level = eb->level[t];
-        int alevel = level < 0 ? -level : level;
-        int deq = (int)quant * (2 * alevel + 1);                   /* rle.rs:130 */
-        int parity = (quant % 2 == 1) ? 0 : -1;                    /* rle.rs:131 */
-        int sg = (level > 0) - (level < 0);
-        int value = clamp_i(sg * (deq + parity), -2048, 2047);     /* rle.rs:133 */
+        /* rle.rs:130-133 as a RELEASE build executes it (what Ruffle ships; [profile.release] has no
+         * overflow-checks, and the dev profile -- which panics on the overflow instead -- is no decoder of such a
+         * stream at all): every operation is i16 and wraps.  For quant * (2|L| + 1) > 32767 (Sorenson's 11-bit
+         * escapes at quantisers from 16 up, parser/block.rs:694-708) the wrapped product, not the mathematical one,
+         * is what reaches the clamp.  i16::abs wraps too (|-32768| = -32768). */
+        int16_t level = eb->level[t];
+        int16_t alevel = wrap_i16(level < 0 ? -(int)level : (int)level);          /* tcoef.level.abs() */
+        int16_t deq = wrap_i16((int)quant * wrap_i16(wrap_i16(2 * (int)alevel) + 1)); /* rle.rs:130 */
+        int16_t parity = (quant % 2 == 1) ? 0 : -1;                               /* rle.rs:131 */
+        int16_t sg = (int16_t)((level > 0) - (level < 0));                        /* i16::signum */
+        int16_t value = wrap_i16((int)sg * wrap_i16((int)deq + parity));          /* rle.rs:133 */
+        value = (int16_t)clamp_i(value, -2048, 2047);
         float val = (float)value;
         data[zy][zx] = val;
         zz += 1;

@@ -54,11 +54,19 @@ def intradc_level(code):
     return 1024 if code == 0xFF else (int(code) << 3)
 
 
+def _wrap_i16(v):
+    """i16 arithmetic of a Rust release build: the value modulo 2^16, as a signed number."""
+    return ((np.asarray(v, dtype=np.int64) + 32768) % 65536) - 32768
+
+
 def dequant(level, quant):
-    """rle.rs:130-133 for an array of non-zero LEVELs (zeros stay zero)."""
+    """rle.rs:130-133 for an array of non-zero LEVELs (zeros stay zero), as a RELEASE build of the reference executes
+    it: every intermediate is an i16 that wraps (a dev build panics on the overflow instead).  quant * (2|L| + 1)
+    exceeds 32767 for Sorenson's 11-bit escape LEVELs at quantisers from 16 up."""
     level = np.asarray(level, dtype=np.int64)
-    mag = quant * (2 * np.abs(level) + 1) - (1 if quant % 2 == 0 else 0)
-    return np.clip(np.sign(level) * mag, -2048, 2047) * (level != 0)
+    mag = _wrap_i16(quant * _wrap_i16(_wrap_i16(2 * _wrap_i16(np.abs(level))) + 1))
+    mag = _wrap_i16(mag - (1 if quant % 2 == 0 else 0))
+    return np.clip(_wrap_i16(np.sign(level) * mag), -2048, 2047) * (level != 0)
 
 
 def classify_dense(coeff, is_intra, intradc_code, coded, kill, quant):

@@ -141,13 +141,18 @@ def _clip(v_bits, pre=None):
     return max(-256, min(255, f32_to_i16(t)))
 
 
+def _wrap_i16(v):
+    """i16 arithmetic of a Rust release build (no overflow checks): modulo 2^16, signed"""
+    return ((v + 32768) & 0xffff) - 32768
+
+
 def dequant(level, quant):
-    """rle.rs:130-133"""
-    m = quant * (2 * abs(level) + 1)
+    """rle.rs:130-133 the way a release build of the reference executes it: every step an i16 that wraps"""
+    m = _wrap_i16(quant * _wrap_i16(_wrap_i16(2 * _wrap_i16(abs(level))) + 1))
     if quant % 2 == 0:
-        m -= 1
-    v = m if level > 0 else -m
-    return max(-2048, min(2047, v))
+        m = _wrap_i16(m - 1)
+    sg = (level > 0) - (level < 0)
+    return max(-2048, min(2047, _wrap_i16(sg * m)))
 
 
 def classify(coeffs):

@@ -42,6 +42,28 @@ void sim_dequant_pairs(const uint32_t *levels, uint32_t n_pairs, uint32_t quant,
     for (uint32_t i = 0; i < n_pairs; i++) out[i] = dequant_pair_i16(levels[i], two_q2, qmp2);
 }
 
+// the wrapping dequantiser of wide rounds (recon_kernel.inl: dequant_pair_wrap): the value itself, any int16 LEVEL
+void sim_dequant_pairs_wrap(const uint32_t *levels, uint32_t n_pairs, uint32_t quant, uint32_t *out)
+{
+    const uint32_t two_q2 = (2u * quant) * 0x00010001u, qmp2 = ((quant - 1u) | 1u) * 0x00010001u;
+    for (uint32_t i = 0; i < n_pairs; i++) out[i] = dequant_pair_wrap(levels[i], two_q2, qmp2);
+}
+
+// the detector of LEVELs outside [-512, 511] (recon_kernel.inl: rowin_wide_bits) on n coefficient rows of 8 int16
+void sim_wide_bits(const uint32_t *rows, uint32_t n_rows, uint32_t *out)
+{
+    for (uint32_t i = 0; i < n_rows; i++) {
+        RowIn ri{};
+        for (int j = 0; j < 4; j++) ri.w[j] = rows[4 * i + j];
+        out[i] = rowin_wide_bits(ri);
+    }
+}
+
+// 1: every IDCT round of sim_recon takes the wide form (which rounds do is a matter of speed only: the results must not
+// change -- tests/test_sim_kernels.py)
+static int force_wide_rounds = 0;
+void sim_force_wide_rounds(int on) { force_wide_rounds = on; }
+
 void sim_layout(uint32_t w, uint32_t h, FrameLayout *out) { *out = make_layout(w, h); }
 
 // block_first_event / events: sparse coefficient transport consumed by the reconstruction wave itself (nullptr: dense)
@@ -96,6 +118,8 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
                 if (ti[l].active) km.act |= 1ull << l;
                 if (ti[l].inter) km.inter |= 1u << (l - MB_LANE0);
                 bad_index = bad_index || ti[l].bad_index;
+                // the strip origin the mark phase packs into the descriptor with literal shifts == the named-constant form
+                if (l < WAVE_TASKS && desc_pix_origin(ti[l].d1) != task_pix_origin(l)) { free(s); return -2; }
             }
             for (int l = 0; l < 64; l++) recon_report(a, l, p.pic, km.inter && !a.has_ref, bad_index);
             for (int l = 0; l < 64; l++) recon_phase_compact(*s, l, ti[l], km.act);
@@ -128,7 +152,13 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
                         if (rc.any) { rows_any |= 1ull << l; rm |= 1u << (l & 7); }
                         if (rc.beyond_first) cols_any |= 1ull << l;
                     }
-                    for (int l = 0; l < 64; l++) recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm), cols_any);
+                    bool wide = false;                                      // as kernels.hip: recon_round_rows
+                    for (int l = 0; l < 64; l++) wide = wide || rowin_wide_bits(ri[l]) != 0;
+                    if (force_wide_rounds) wide = true;
+                    for (int l = 0; l < 64; l++) {
+                        if (wide) recon_phase_idct_rows<false, true>(*s, ri[l], l, cols_from_mask(wm), cols_any);
+                        else recon_phase_idct_rows(*s, ri[l], l, cols_from_mask(wm), cols_any);
+                    }
                     for (int l = 0; l < 64; l++) any_special = any_special || recon_block_is_special(ri[l], l, rows_any, cols_any);
                 }
                 if (round == 0) {

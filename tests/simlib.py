@@ -102,16 +102,18 @@ def recon(w, h, mbs, coeffs, ref=None, asan=False, events=False):
         cur = np.full(L.frame_bytes, 0xC3, np.uint8)
         status = np.zeros(1, np.uint32)
         dummy = np.zeros((1, 64), np.int16)
-        lib(asan).sim_recon_ex(w, h, 1, _p(mbs), _p(dummy), coeffs.shape[0], None, _p(reff), 1 if ref is not None else 0,
-                               _p(cur), _p(status), _p(first), _p(ev))
+        rc = lib(asan).sim_recon_ex(w, h, 1, _p(mbs), _p(dummy), coeffs.shape[0], None, _p(reff), 1 if ref is not None else 0,
+                                    _p(cur), _p(status), _p(first), _p(ev))
+        assert rc == 0, "sim_recon_ex: %d (-2: desc_pix_origin != task_pix_origin)" % rc
         return int(status[0]), unpack_frame(L, cur)
     cpad = np.zeros((coeffs.shape[0] + 1, 64), np.int16)
     cpad[:coeffs.shape[0]] = coeffs
     reff = pack_frame(L, ref) if ref is not None else None
     cur = np.full(L.frame_bytes, 0xC3, np.uint8)
     status = np.zeros(1, np.uint32)
-    lib(asan).sim_recon(w, h, 1, _p(mbs), _p(cpad), coeffs.shape[0], None, _p(reff), 1 if ref is not None else 0,
-                        _p(cur), _p(status))
+    rc = lib(asan).sim_recon(w, h, 1, _p(mbs), _p(cpad), coeffs.shape[0], None, _p(reff), 1 if ref is not None else 0,
+                             _p(cur), _p(status))
+    assert rc == 0, "sim_recon: %d (-2: desc_pix_origin != task_pix_origin)" % rc
     return int(status[0]), unpack_frame(L, cur)
 
 

@@ -98,3 +98,22 @@ def test_dequantiser_mutant_is_caught_by_the_every_level_test():
     good = subprocess.run(cmd, env=dict(os.environ, H263MI_LIB=os.path.join(PKG, "libh263mi.so")), capture_output=True,
                           text=True, timeout=600)
     assert good.returncode == 0 and "1 passed" in good.stdout, good.stdout[-800:]
+
+
+def test_wrap_mutant_is_caught_by_the_11_bit_level_test():
+    """libh263mi_wrap.so: the dequantiser of rounds with LEVELs outside [-512, 511] uses a SATURATING multiply-add, i.e.
+    clamps the mathematical product where a release build of the reference clamps the wrapped i16 one (rle.rs:130-133;
+    recon_kernel.inl: dequant_pair_wrap) -- round 1-4's behaviour.  The 11-bit LEVEL sweep and the hand-derived known
+    answers of tests/test_gpu_round5.py must fail on it and pass on the product (fresh processes: the library is chosen at
+    import)."""
+    lib = os.path.join(PKG, "mutants", "libh263mi_wrap.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", PKG, "-s", "mutants"])
+    for key, n in (("hand_derived", 1), ("every_11_bit and dense", 1)):
+        cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_round5.py"), "-x", "-q", "-k", key,
+               "-p", "no:cacheprovider"]
+        bad = subprocess.run(cmd, env=dict(os.environ, H263MI_LIB=lib), capture_output=True, text=True, timeout=600)
+        assert bad.returncode != 0 and "1 failed" in bad.stdout, bad.stdout[-800:]
+        good = subprocess.run(cmd, env=dict(os.environ, H263MI_LIB=os.path.join(PKG, "libh263mi.so")), capture_output=True,
+                              text=True, timeout=600)
+        assert good.returncode == 0 and "%d passed" % n in good.stdout, good.stdout[-800:]

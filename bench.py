@@ -114,7 +114,8 @@ def launch_ranks(args, argv):
 class Workload:
     """Device-resident records of `gop` frame indices for `n` streams."""
 
-    def __init__(self, h263mi, n, gop, first_stream, device_id, stream, i_kind=None, p_frames=True, events=False):
+    def __init__(self, h263mi, n, gop, first_stream, device_id, stream, i_kind=None, p_frames=True, events=False, stream_stride=1):
+        """picture p of the batch is stream first_stream + p * stream_stride (strong scaling deals stream s to GPU s mod N)"""
         i_kind = h263mi.SYNTH_I_MIXED if i_kind is None else i_kind
         self.n, self.frames, self.h263mi, self.events = n, [], h263mi, events
         for f in range(gop):
@@ -124,7 +125,7 @@ class Workload:
             d_co = h263mi.DeviceBuffer(cap * 128, device_id)
             d_base = h263mi.DeviceBuffer(n * 8, device_id)
             blocks = h263mi.synth_batch_device(kind, W, H, n, first_stream, f, d_mbs.ptr, d_co.ptr, cap, d_base.ptr,
-                                               device_id, stream)
+                                               device_id, stream, stream_stride)
             ptype = h263mi.PICTURE_I if kind != h263mi.SYNTH_P else h263mi.PICTURE_P
             fr = dict(kind=kind, ptype=ptype, mbs=d_mbs, co=d_co, base=d_base, blocks=blocks)
             if events:
@@ -194,24 +195,28 @@ class Workload:
         return self.n * RGBA_BYTES
 
 
-def run_frames(batch, wl, d_rgba, n_frames, pipeline=False):
+def run_frames(batch, wl, d_rgba, n_frames, pipeline=False, checked=False):
     """n_frames frame indices starting at a GOP boundary (every GOP re-starts all streams with an I picture).
     pipeline: h263mi_batch_decode on a H263MI_CFG_PIPELINE_POST batch -- one launch per frame index reconstructs
-    picture f and post-processes picture f - 1; the last picture's post-processing runs at the next sync."""
+    picture f and post-processes picture f - 1; the last picture's post-processing runs at the next sync.
+    checked: the calls say how large their arrays are (coeff_pool_blocks, n_events), as every host entry point does: the
+    waves then refuse to read a coded block outside the pool / an event list whose bounds do not ascend or reach beyond
+    the events (include/h263mi.h).  Without it the caller vouches for its arrays and the waves check nothing."""
     g = len(wl.frames)
     for i in range(n_frames):
         fr = wl.frames[i % g]
+        pool = fr["blocks"] if checked else 0
         if pipeline and wl.events and fr.get("first") is not None:
-            batch.decode_events(fr["ptype"], fr["mbs"].ptr, fr["first"].ptr, fr["ev"].ptr, fr["base"].ptr, 0, STRENGTH,
-                                d_rgba.ptr, None)
+            batch.decode_events(fr["ptype"], fr["mbs"].ptr, fr["first"].ptr, fr["ev"].ptr, fr["base"].ptr, pool, STRENGTH,
+                                d_rgba.ptr, None, n_events=fr["n_events"] if checked else 0)
         elif pipeline:
-            batch.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, 0, STRENGTH, d_rgba.ptr, None)
+            batch.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, pool, STRENGTH, d_rgba.ptr, None)
         else:
             batch.submit(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr)
             batch.render_rgba(STRENGTH, d_rgba.ptr, None)
 
 
-def parity_gate(h263mi, batch, d_rgba, first_stream, n, gop, streams=PARITY_STREAMS):
+def parity_gate(h263mi, batch, d_rgba, first_stream, n, gop, streams=PARITY_STREAMS, stream_stride=1):
     """BASELINE.md section 3 "parity gate": the batch has just decoded whole GOPs; its last picture (frame index
     gop-1, after gop-1 chained P pictures) of a few streams must equal the oracle's, planes and RGBA, bit for bit.
     The oracle is the checker here -- it is never on the timed or shipped path."""
@@ -224,7 +229,7 @@ def parity_gate(h263mi, batch, d_rgba, first_stream, n, gop, streams=PARITY_STRE
         ref = None
         for f in range(gop):
             kind = h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P
-            mbs, co = h263mi.synth_picture_host(kind, W, H, first_stream + s, f)
+            mbs, co = h263mi.synth_picture_host(kind, W, H, first_stream + s * stream_stride, f)
             rc, ref = orc.decode_picture(W, H, mbs, co, ref)
             if rc != 0:
                 return "oracle error %d (stream %d frame %d)" % (rc, s, f), checked
@@ -237,7 +242,7 @@ def parity_gate(h263mi, batch, d_rgba, first_stream, n, gop, streams=PARITY_STRE
         rgba = d_rgba.download(RGBA_BYTES, s * RGBA_BYTES)
         if not np.array_equal(rgba, want):
             return "stream %d: RGBA differs from the oracle in %d bytes" % (s, int((rgba != want).sum())), checked
-        checked.append(first_stream + s)
+        checked.append(first_stream + s * stream_stride)
     return "ok", checked
 
 
@@ -445,7 +450,8 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
     pps = pics / dt
     gop_bytes = sum(len(streams[s % n_distinct][f]) for s in range(n) for f in order)
     p_mean = int(p_bytes / max(n_frames - 1, 1))
-    out = {"pictures_per_s": round(pps, 1), "mp_per_s": round(pps * MP_PER_PICTURE, 1),
+    out = {"_pictures": pics, "_seconds": dt,
+           "pictures_per_s": round(pps, 1), "mp_per_s": round(pps * MP_PER_PICTURE, 1),
            "realtime_1080p30_streams": round(pps / 30.0, 1), "parity_vs_oracle": "ok" if ok else "MISMATCH",
            "parser_threads": cores, "gops_timed": reps, "bitstream_mb_per_s": round(gop_bytes * reps / dt / 1e6, 1),
            "one_parser_thread_pictures_per_s": round(n * len(order) / dt1, 1),
@@ -593,12 +599,25 @@ def stub_main(args, rank, world):
     else:
         dist = None
     elapsed = shard.timed_region(dist, lambda: time.sleep(0.01 * args.steps))
-    per_rank = args.total_streams // world if args.total_streams else args.streams
-    pictures = shard.aggregate_pictures(dist, per_rank * args.steps * args.gop * args.gops_per_step)
+    strong = args.total_streams > 0
+    mine = shard.streams_of_rank(rank, world, args.streams, total_streams=args.total_streams if strong else None)
+    pictures = shard.aggregate_pictures(dist, len(mine) * args.steps * args.gop * args.gops_per_step)
+    # the end-to-end leg of every rank (stand-in: rank r "decodes" 100 * (r + 1) pictures in 0.1 * (r + 1) s) and the host
+    # thread budget of a rank, through the same functions main() uses
+    threads = shard.parser_threads_for_rank(physical_cores()[0], world)
+    e2e_rate, e2e_units, e2e_seconds = shard.aggregate_rate(dist, 100 * (rank + 1), 0.1 * (rank + 1))
+    all_streams = [None] * world
+    if dist is not None:
+        dist.all_gather_object(all_streams, mine)
+    else:
+        all_streams = [mine]
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": pictures * MP_PER_PICTURE / elapsed, "unit": "MP/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "data": "stub (no GPU work)",
-                          "pictures": pictures}), flush=True)
+                          "pictures": pictures, "scaling": "strong" if strong else "weak",
+                          "streams_of_rank": all_streams, "parser_threads_per_rank": threads,
+                          "cpu_budget": physical_cores()[0], "local_world_size": shard.local_world_size(world),
+                          "e2e": {"pictures_per_s": e2e_rate, "pictures": e2e_units, "seconds": e2e_seconds}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0
@@ -639,16 +658,22 @@ def main(argv=None):
         # "nccl" is RCCL on ROCm; rank / world size are passed explicitly so that the forced single-rank form needs no
         # launcher environment
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # waits that may last seconds (another rank is busy on its HOST) go through a gloo group: a socket wait, where a RCCL
+    # barrier spins a host thread per waiting rank
+    host_pg = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
 
     stream = torch.cuda.current_stream().cuda_stream
     strong = args.total_streams > 0
     if strong and args.total_streams % world:
         raise SystemExit("--total-streams %d is not a multiple of %d GPUs" % (args.total_streams, world))
     n = args.total_streams // world if strong else args.streams
-    my_streams = shard.streams_of_rank(rank, world, n)           # weak scaling: 64 streams per GPU; strong: total / GPUs
+    # weak scaling: rank r owns the 64 streams r * 64 ...; strong: stream s of the T is pinned to GPU s mod N
+    my_streams = shard.streams_of_rank(rank, world, n, total_streams=args.total_streams if strong else None)
+    stride = world if strong else 1
+    assert len(my_streams) == n and all(my_streams[k] == my_streams[0] + k * stride for k in range(n))
     pipeline = not args.no_pipeline and not args.overlap
     use_events = pipeline and not args.dense_coeffs
-    wl = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream, events=use_events)
+    wl = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream, events=use_events, stream_stride=stride)
     batch = h263mi.Batch(n, W, H, local_rank, stream, overlap_post=args.overlap, pipeline_post=pipeline)
     d_rgba = h263mi.DeviceBuffer(n * RGBA_BYTES, local_rank)
     frames_per_step = args.gop * args.gops_per_step
@@ -673,7 +698,7 @@ def main(argv=None):
     # ---- parity gate (outside the timed region): every rank checks its own streams; any failure fails the job
     gate, gate_streams = ("skipped", [])
     if not args.no_parity_gate:
-        gate, gate_streams = parity_gate(h263mi, batch, d_rgba, my_streams[0], n, args.gop)
+        gate, gate_streams = parity_gate(h263mi, batch, d_rgba, my_streams[0], n, args.gop, stream_stride=stride)
     gate_bad = 0 if gate in ("ok", "skipped") else 1
     if dist is not None:
         t = torch.tensor([gate_bad], dtype=torch.int32, device="cuda")
@@ -711,11 +736,12 @@ def main(argv=None):
     # HBM traffic of that kernel: FETCH_SIZE + WRITE_SIZE from the separate rocprofv3 --pmc passes of
     # tools/prof_final.sh, committed under profiles/.  It cannot be measured from inside this process, so it is
     # reported only when the committed figure was taken on exactly this kernel source.
-    traffic, traffic_source = None, None
+    traffic, traffic_source, valu_pmc = None, None, None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if n == 64 and tr.get("kernel_source_hash") == kernel_source_hash():
             traffic = tr["kernels"][dom]["hbm_bytes_per_launch"]
+            valu_pmc = (tr.get("valu") or {}).get(dom)
             traffic_source = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
                              "workload, %s, kernel sources %s)" % (tr.get("tag", "?"), tr["kernel_source_hash"])
         else:
@@ -762,11 +788,63 @@ def main(argv=None):
                                 "alg_bytes_per_launch": int(v["alg_bytes_per_launch"]),
                                 "achieved_gbs": round(v["achieved_gbs"], 1)} for k, v in kernels.items()},
                 "k_recon_p_alg_bytes_per_launch": int(recon_alg_p)}
+    # What bounds the launch in fact: the vector ALUs' issue slots, not HBM.  From the committed PMC passes of
+    # tools/prof_final.sh over exactly these kernel sources (hash-tied like `traffic`): vector instructions per launch, the
+    # lane operations that is per output pixel, the share of the launch's cycles the vector ALUs were busy -- and the time
+    # that share is of THIS run's launches.  `bound` stays "hbm" (the byte roofline this line is quoted on); `bound_observed`
+    # says which unit is nearest its limit.
+    pixels_per_launch = n * W * H
+    if valu_pmc:
+        busy = valu_pmc["busy_frac"]
+        roofline["valu"] = {"insts_per_launch": int(valu_pmc["insts_per_launch"]),
+                            "lane_ops_per_pixel": round(valu_pmc["insts_per_launch"] * 64.0 / pixels_per_launch, 2),
+                            "busy_frac": round(busy, 4),
+                            "alu_time_ms": round(busy * kernels[dom]["avg_ms"], 4),
+                            "hbm_busy_frac": round(ach / peak_copy, 4) if peak_copy else None,
+                            "source": "profiles/traffic_latest.json `valu` (rocprofv3 --pmc SQ_INSTS_VALU / VALUBusy passes of "
+                                      "tools/prof_final.sh, %s, kernel sources %s): mean over the launches of the profiled GOPs; "
+                                      "alu_time_ms = busy_frac x this run's avg_launch_ms; hbm_busy_frac = achieved / this box's copy "
+                                      "ceiling" % (tr.get("tag", "?"), tr["kernel_source_hash"])}
+        roofline["bound_observed"] = "valu" if (peak_copy and busy > ach / peak_copy) else "hbm"
+    else:
+        roofline["valu"] = None
+        roofline["bound_observed"] = None
+
+    def ms_per_frame_index(workload, n_frames, checked):
+        run_frames(batch, workload, d_rgba, args.gop, pipeline, checked)
+        batch.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_frames(batch, workload, d_rgba, n_frames, pipeline, checked)
+        batch.sync()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n_frames * 1e3
+
+    if not args.no_extra and pipeline:
+        # The timed region hands its arrays over WITHOUT their sizes (n_events = 0, coeff_pool_blocks = 0: "the caller
+        # vouches", include/h263mi.h) -- they are this process's own generator output.  Every host entry point, the path
+        # real streams take, passes both, and the waves then bounds-check every coded block and event list they read.  The
+        # same frames both ways, interleaved, right here:
+        pairs = [(ms_per_frame_index(wl, 2 * frames_per_step, False), ms_per_frame_index(wl, 2 * frames_per_step, True))
+                 for _ in range(2)]
+        vouched = sum(p_[0] for p_ in pairs) / len(pairs)
+        checked_ms = sum(p_[1] for p_ in pairs) / len(pairs)
+        roofline["checked_mode"] = {"ms_per_frame_index": round(checked_ms, 4), "vouched_ms_per_frame_index": round(vouched, 4),
+                                    "cost": round(checked_ms / vouched - 1.0, 4),
+                                    "mp_per_s": round(n * MP_PER_PICTURE / (checked_ms * 1e-3), 1),
+                                    "what": "the timed workload with coeff_pool_blocks and n_events given to "
+                                            "h263mi_batch_decode[_events] (what every host entry point does) against the headline's "
+                                            "calls, which vouch for their arrays; 2 x %d frame indices each, interleaved twice, "
+                                            "wall clock" % (2 * frames_per_step)}
+    else:
+        roofline["checked_mode"] = None
 
     extra = {}
-    if rank == 0 and world == 1 and not args.no_extra and use_events:
+    # (the extra legs run on EVERY rank -- each on its own GPU and its own share of the host -- so that no rank sits in a
+    # collective while another measures; rank 0 reports its own figures, the end-to-end leg the sum over the ranks)
+    if not args.no_extra and use_events:
         # the same workload with the coefficients as dense 128-byte blocks in HBM (round 1-2's transport)
-        wld = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream, events=False)
+        wld = Workload(h263mi, n, args.gop, my_streams[0], local_rank, stream, events=False, stream_stride=stride)
         run_frames(batch, wld, d_rgba, args.gop, pipeline)
         batch.sync()
         torch.cuda.synchronize()
@@ -785,7 +863,7 @@ def main(argv=None):
             for k in ("mbs", "co", "base"):
                 fr[k].free()
         del wld
-    if rank == 0 and world == 1 and not args.no_extra:
+    if not args.no_extra:
         # BASELINE configs[1]: dense 1080p I pictures (every block Full): dequant + IDCT + YUV->RGBA, no deblock
         del wl
         dense = Workload(h263mi, n, 1, 0, local_rank, stream, i_kind=h263mi.SYNTH_I_DENSE, p_frames=False)
@@ -825,12 +903,47 @@ def main(argv=None):
                     res.update({"mp_per_s": res["two_launches_mp_per_s"], "pipeline_gbs": round(alg * reps / dt / 1e9, 1),
                                 "pipeline_frac": round(alg * reps / dt / 1e9 / HBM_PEAK_GBS, 4)})
         extra["config2_dense_iframe"] = res
+        # BASELINE's second single-GPU configuration where the driver keeps it: inside `roofline`
+        if "k_frame_avg_ms" in res:
+            roofline["config2_dense_i"] = {
+                "ms_per_64": res["k_frame_avg_ms"] * 64.0 / n, "pictures_per_launch": n,
+                "alg_bytes_per_launch": int(alg),
+                "achieved": round(alg / (res["k_frame_avg_ms"] * 1e-3) / 1e9, 1),
+                "frac": round(alg / (res["k_frame_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "mp_per_s": res["mp_per_s"],
+                "what": "BASELINE configs[1]: %d dense 1920x1080 I pictures (every block Full) per launch, dequant + IDCT + "
+                        "BT.601 RGBA (no deblock), k_frame: HIP-event mean over %d launches; algorithmic bytes = records + "
+                        "128 B per coded block + planes + RGBA written" % (n, reps)}
+    roofline.setdefault("config2_dense_i", None)
 
-    if rank == 0 and world == 1 and not args.no_extra and not args.no_e2e:
-        extra["e2e_bitstream"] = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba)
-        extra["e2e_bitstream_realistic"] = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba, realistic=True)
-        extra["plain_functions_1080p"] = plain_function_latency(h263mi)
-        extra["single_stream_1080p"] = single_stream_latency(h263mi, local_rank, stream)
+    e2e_bad = 0
+    if not args.no_extra and not args.no_e2e:
+        # every rank runs its own 64 streams end to end, on ITS share of the container's CPUs, all at the same time
+        threads = shard.parser_threads_for_rank(physical_cores()[0], world)
+        if dist is not None:
+            dist.barrier()
+        for key, realistic in (("e2e_bitstream", False), ("e2e_bitstream_realistic", True)):
+            e = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba, parser_threads=threads, realistic=realistic)
+            rate, units, seconds = shard.aggregate_rate(dist, e.pop("_pictures"), e.pop("_seconds"))
+            if world > 1:
+                e["all_ranks"] = {"pictures_per_s": round(rate, 1), "realtime_1080p30_streams": round(rate / 30.0, 1),
+                                  "pictures": units, "seconds_slowest_rank": round(seconds, 4), "ranks": world,
+                                  "parser_threads_per_rank": threads,
+                                  "what": "every rank its own %d streams on its own GPU and %d parser threads, all ranks at the "
+                                          "same time: pictures of all ranks / the slowest rank's time; the other fields of this "
+                                          "object are rank 0's own" % (n, threads)}
+            e2e_bad |= e["parity_vs_oracle"] != "ok"
+            extra[key] = e
+        if rank == 0:
+            extra["plain_functions_1080p"] = plain_function_latency(h263mi)
+            extra["single_stream_1080p"] = single_stream_latency(h263mi, local_rank, stream)
+            e2e_bad |= extra["single_stream_1080p"]["parity_vs_oracle"] != "ok"
+        if host_pg is not None:
+            dist.barrier(group=host_pg)          # (rank 0's single-stream leg: the others wait on a socket)
+    if dist is not None:
+        t = torch.tensor([int(e2e_bad)], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2e_bad = int(t.item())
 
     out = {
         "metric": "decoded megapixels/sec (IDCT+MC+YUV->RGB)",
@@ -842,7 +955,8 @@ def main(argv=None):
                                "over the resident input = %d GOPs x %d frame indices = %d pictures per stream (%d per "
                                "step and GPU); GOP = 1 I (mixed block classes) + %d P (half-pel MVs in [-32,31], 25%% "
                                "coded blocks, quant 10); dequant+IDCT+MC+add/clip, deblock strength %d, BT.601 RGBA; "
-                               "records pre-generated in HBM, coefficients %s" % (
+                               "records pre-generated in HBM (the calls vouch for their arrays: no pool size / event count "
+                               "given, roofline.checked_mode has the other way), coefficients %s" % (
                                    n, args.gops_per_step, args.gop, frames_per_step, n * frames_per_step, args.gop - 1, STRENGTH,
                                    "as sparse events (one 32-bit word per non-zero LEVEL: the host parser's transport form, "
                                    "h263mi_batch_decode_events) for the P pictures, dense blocks for the GOP's I picture" if use_events else "as dense int16[64] blocks (h263mi_batch_decode)"),
@@ -854,22 +968,26 @@ def main(argv=None):
         "ms_per_frame_index": round(elapsed / max(args.steps * frames_per_step, 1) * 1e3, 4),
         "realtime_1080p30_streams": round(value / (MP_PER_PICTURE * 30), 1),
         "parity_gate": gate, "parity_gate_streams": gate_streams,
+        "e2e_parity": None if (args.no_extra or args.no_e2e) else ("MISMATCH" if e2e_bad else "ok"),
         "roofline": roofline,
     }
     if extra:
         out["extra"] = extra
-    if rank == 0 and not args.no_cpu_baseline:
-        # (N > 1: timed on rank 0 while the other ranks wait at the final barrier -- their host threads are idle)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(h263mi)
     elif rank == 0:
+        # N > 1: the CPU baseline is a property of the box, not of the job; it is timed at N = 1 only (there the host is
+        # idle beside it -- with N ranks their threads would compete with its `cores` threads)
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     batch.close()
     if dist is not None:
-        dist.barrier()                  # (rank 0 has just spent ~30 s on the CPU baseline: nobody leaves before it is back)
+        if host_pg is not None:
+            dist.barrier(group=host_pg)
         dist.destroy_process_group()
-    return 1 if gate_bad else 0
+    # a mismatch anywhere -- the main gate or an end-to-end leg, on any rank -- fails the run
+    return 1 if (gate_bad or e2e_bad) else 0
 
 
 if __name__ == "__main__":

@@ -2440,6 +2440,15 @@ int h263mi_synth_batch_device(const h263mi_backend_cfg *cfg, int kind, uint16_t 
                               int16_t *d_coeffs, size_t coeff_capacity_blocks, uint64_t *d_coeff_base,
                               size_t *total_blocks)
 {
+    return h263mi_synth_batch_device_strided(cfg, kind, width, height, n_streams, first_stream_id, 1, frame_idx, d_mbs, d_coeffs,
+                                             coeff_capacity_blocks, d_coeff_base, total_blocks);
+}
+
+int h263mi_synth_batch_device_strided(const h263mi_backend_cfg *cfg, int kind, uint16_t width, uint16_t height,
+                                      uint32_t n_streams, uint32_t first_stream_id, uint32_t stream_stride, uint32_t frame_idx,
+                                      h263mi_mb_record *d_mbs, int16_t *d_coeffs, size_t coeff_capacity_blocks,
+                                      uint64_t *d_coeff_base, size_t *total_blocks)
+{
     if (kind < 0 || kind > H263MI_SYNTH_P || !width || !height || !n_streams || !d_mbs || !d_coeffs || !d_coeff_base)
         return H263MI_ERR_INVALID_ARGUMENT;
     const int dev = cfg ? cfg->device_id : 0;
@@ -2451,6 +2460,7 @@ int h263mi_synth_batch_device(const h263mi_backend_cfg *cfg, int kind, uint16_t 
     a.kind = kind;
     a.n_streams = n_streams;
     a.first_stream_id = first_stream_id;
+    a.stream_stride = stream_stride;
     a.frame_idx = frame_idx;
     a.mbs_per_picture = L.mbw * L.mbh;
     a.mbs = d_mbs;

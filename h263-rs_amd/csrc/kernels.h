@@ -10,6 +10,7 @@ namespace h263mi {
 struct SynthArgs {
     int kind;
     uint32_t n_streams, first_stream_id, frame_idx, mbs_per_picture;
+    uint32_t stream_stride;     // picture p is stream first_stream_id + p * stream_stride (1: consecutive ids)
     MbRecord *mbs;              // device, n_streams * mbs_per_picture
     uint32_t *counts;           // device scratch, one per macroblock
     uint32_t *totals;           // device, coded blocks per picture

@@ -177,7 +177,7 @@ __device__ __forceinline__ void recon_round_rows(const ReconArgs &a, ReconWave &
     // A LEVEL outside [-512, 511] anywhere in the round (one ballot): the reference's i16 dequantiser may have overflowed,
     // and the round takes the wrapping form of the row pass (recon_kernel.inl: dequant_pair_wrap) -- hostile or broken
     // streams only, but bit for bit what a release build of the reference makes of them.
-    const bool wide = __ballot(rowin_wide_bits(rs.ri) != 0) != 0;
+    const bool wide = __ballot(rs.ri.wide != 0) != 0;
     rs.dense = !wide && __ballot(rs.ri.w[3] != 0) == ~0ull;
     if (rs.dense) {
         wave_fence();                       // the column pass of the previous round has read tbuf
@@ -601,7 +601,7 @@ __global__ void k_synth_headers(SynthArgs a)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n_streams * a.mbs_per_picture) return;
     const uint32_t p = g / a.mbs_per_picture, mb = g % a.mbs_per_picture;
-    MbRecord r = synth_mb_header(a.kind, a.first_stream_id + p, a.frame_idx, mb);
+    MbRecord r = synth_mb_header(a.kind, a.first_stream_id + p * a.stream_stride, a.frame_idx, mb);
     a.mbs[g] = r;
     a.counts[g] = (uint32_t)__popc(r.cbp);
 }
@@ -639,7 +639,7 @@ __global__ void k_synth_coeffs(SynthArgs a)
     const MbRecord r = a.mbs[gm];
     if (!((r.cbp >> blk) & 1)) return;
     int16_t c[64];
-    synth_block_coeffs(a.kind, a.first_stream_id + p, a.frame_idx, mb, (int)blk, c);
+    synth_block_coeffs(a.kind, a.first_stream_id + p * a.stream_stride, a.frame_idx, mb, (int)blk, c);
     const uint64_t idx = a.coeff_base[p] + r.coeff_index + (uint64_t)__popc(r.cbp & ((1u << blk) - 1u));
     uint4 *dst = reinterpret_cast<uint4 *>(a.coeffs + idx * 64);
 #pragma unroll

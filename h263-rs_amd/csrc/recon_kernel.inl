@@ -378,7 +378,7 @@ H263_HD int rows_from_mask(uint32_t row_mask)       // bit r: some block has a n
 // VALID ONLY WHERE THE REFERENCE'S i16 ARITHMETIC DOES NOT OVERFLOW: rle.rs:130-133 multiplies in i16, and a release build
 // (what Ruffle ships) WRAPS where q * (2|L| + 1) exceeds 32767 -- reachable with Sorenson's 11-bit escape LEVELs from q = 16
 // up (parser/block.rs:694-708) -- so the wrapped product, not the mathematical one, is what it clamps.  No |L| <= 511
-// overflows at any quantiser (31 * 1023 = 31713); a round that holds a wider LEVEL (rowin_wide_bits, one ballot) takes
+// overflows at any quantiser (31 * 1023 = 31713); a round that holds a wider LEVEL (RowIn::wide, one ballot) takes
 // dequant_pair_wrap below instead.
 // `two_q2`, `qmp2`: 2q and q - parity in both halves of a dword (2q <= 62, q - parity <= 31: times 16 they fit 10 bits).
 constexpr float DEQUANT_SCALE = 16.0f;
@@ -414,7 +414,7 @@ H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qm
 // so does this form), then the clamp to [-2048, 2047]: a multiply-add WITHOUT saturation, a max and a min.  Returns the
 // value itself (not 16 x): the row pass of such a round uses the unscaled table.  Examples: q = 31, L = -1024: 31 * 2049 =
 // 63519 = -2017 (mod 2^16), times -1 -> +2017; q = 31, L = 529: 32829 = -32707 -> -2048 (where the mathematical product
-// would clamp to +2047).  Only rounds that hold a LEVEL outside [-512, 511] come here (rowin_wide_bits).
+// would clamp to +2047).  Only rounds that hold a LEVEL outside [-512, 511] come here (RowIn::wide).
 H263_DEV uint32_t dequant_pair_wrap(uint32_t levels, uint32_t two_q2, uint32_t qmp2)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -778,8 +778,26 @@ struct RowIn {
                                // the caller zeroes it in front of the first round and reports it behind the last)
     uint32_t w[4];             // the 8 LEVELs of the lane's coefficient row (zeros when the block has no TCOEF)
     uint32_t d1;               // descriptor word 1 of the lane's block (quantiser, INTRADC level, intra, task)
+    uint32_t wide;             // non-zero: some LEVEL the lane handled in this round lies outside [-512, 511] (see wide_bits_of)
     bool     active;           // the lane's slot holds a block in this round
 };
+
+// A LEVEL outside [-512, 511] -- the only kind that can overflow the reference's i16 product (dequant_pair_i16) -- has
+// bits 15..9 that are not all equal.  Bit k of w ^ (w + w) is bit k ^ bit k - 1 of w: for a pair of LEVELs in a dword the
+// bits 15..10 and 31..26 answer for the two halves (the bit the low half's doubling pushes into the high half lands on bit
+// 16, outside the mask); for an event word (LEVEL in the high half) bits 31..26.  Two instructions of the 2-cycle class per
+// word; the caller ORs the words of a round together and masks once.
+constexpr uint32_t WIDE_MASK_PAIR = 0xfc00fc00u, WIDE_MASK_EVENT = 0xfc000000u;
+H263_DEV uint32_t wide_bits_of(uint32_t w)
+{
+    uint32_t twice;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_add_u32 %0, %1, %1" : "=v"(twice) : "v"(w));       // (written as w << 1 it becomes the 4-cycle v_lshlrev)
+#else
+    twice = w + w;
+#endif
+    return w ^ twice;
+}
 
 // Sparse transport: the coefficient rows of a round straight from the EVENTS of its 8 blocks (one 32-bit word per
 // non-zero LEVEL, the form the host parser emits and the PCIe link carries) -- what k_expand used to turn into a dense
@@ -793,16 +811,18 @@ struct RowIn {
 // `stage`: -1 = the three steps one after the other (the device: the wave's lanes run in lock step and the fences order
 // the steps); 0, 1, 2 = one step only (the CPU logic checker runs the lanes one after the other and therefore each step
 // over all lanes before the next).
+// `wide`: receives wide_bits_of over the events this lane placed (masked: non-zero = a LEVEL outside [-512, 511]) -- two
+// instructions per event here instead of twelve per coefficient row behind it.
 H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const WavePos &p, uint32_t d0, bool has, int lane,
-                                     uint32_t w[4], uint32_t *bad_events, int stage = -1, bool bounds_known = false,
-                                     uint32_t known_first = 0, uint32_t known_next = 0)
+                                     uint32_t w[4], uint32_t *bad_events, uint32_t *wide, int stage = -1,
+                                     bool bounds_known = false, uint32_t known_first = 0, uint32_t known_next = 0)
 {
     const int slot = lane >> 3, r = lane & 7;
     int16_t *dense = reinterpret_cast<int16_t *>(s.tbuf);       // [8 slots][64 positions]
     if (stage < 0 || stage == 0) *reinterpret_cast<uint4 *>(dense + lane * 8) = make_uint4(0, 0, 0, 0);
     if (stage < 0 || stage == 1) {
         uint32_t at = 0, end = 0;
-        uint32_t bad = 0;
+        uint32_t bad = 0, wd = 0;
         const bool told = a.n_events != 0xffffffffu;            // uniform
         if (has) {
             const uint32_t *fe = a.block_first_event + (p.cbase + (d0 >> 7));
@@ -829,8 +849,10 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
 #pragma unroll
             for (int j = 0; j < 8; j++) ev[j] = at + 8u * (uint32_t)j < end ? a.events[at + 8u * (uint32_t)j] : 0u;
 #pragma unroll
-            for (int j = 0; j < 8; j++)
+            for (int j = 0; j < 8; j++) {
                 if (at + 8u * (uint32_t)j < end) dense[slot * 64 + (int)(ev[j] & 63u)] = (int16_t)(ev[j] >> 16);
+                wd |= wide_bits_of(ev[j]);                      // (a word that was not read is 0)
+            }
             at += 64u;
         }
         while (__ballot(at < end) != 0) {
@@ -840,9 +862,11 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
             if (at < end) {
                 const uint32_t ev = a.events[at];
                 dense[slot * 64 + (int)(ev & 63u)] = (int16_t)(ev >> 16);
+                wd |= wide_bits_of(ev);
             }
             at += 8u;
         }
+        *wide = wd & WIDE_MASK_EVENT;
         wave_fence();                                           // all LEVELs of the round are in place
     }
     if (stage < 0 || stage == 2) {
@@ -874,7 +898,7 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     }
     const bool has = ri.active && d0 != NO_COEFFS;
     if (a.events) {                                             // uniform
-        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, &ri.bad_events, events_stage, round == 0, raw.x, raw.y);
+        coeff_rows_from_events(a, s, p, d0, has, lane, ri.w, &ri.bad_events, &ri.wide, events_stage, round == 0, raw.x, raw.y);
         return;
     }
     if (round > 0) {
@@ -888,32 +912,13 @@ H263_DEV void recon_phase_idct_load(const ReconArgs &a, ReconWave &s, const Wave
     asm volatile("" : "+v"(keep));
 #endif
     ri.w[0] = raw.x & keep; ri.w[1] = raw.y & keep; ri.w[2] = raw.z & keep; ri.w[3] = raw.w & keep;
+    ri.wide = (wide_bits_of(ri.w[0]) | wide_bits_of(ri.w[1]) | wide_bits_of(ri.w[2]) | wide_bits_of(ri.w[3])) & WIDE_MASK_PAIR;
 }
 
 // lane's contribution to cols_from_mask
 H263_DEV uint32_t rowin_word_mask(const RowIn &ri)
 {
     return (ri.w[1] ? 2u : 0u) | (ri.w[2] ? 4u : 0u) | (ri.w[3] ? 8u : 0u);
-}
-
-// Non-zero when some LEVEL of the lane's coefficient row lies outside [-512, 511] -- bits 15..9 of a half are not all
-// equal: bit k of w ^ (w + w) is L[k] ^ L[k - 1] (the bit the low half's shift pushes into the high half lands on bit 16,
-// outside the mask).  Only such a LEVEL can overflow the reference's i16 product (dequant_pair_i16); the round then
-// dequantises with dequant_pair_wrap.  Eight adds / xors, three ors and one and per row (the 2-cycle class).
-H263_DEV uint32_t rowin_wide_bits(const RowIn &ri)
-{
-    uint32_t t = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        uint32_t twice;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm("v_add_u32 %0, %1, %1" : "=v"(twice) : "v"(ri.w[j]));       // (written as w << 1 it becomes the 4-cycle v_lshlrev)
-#else
-        twice = ri.w[j] + ri.w[j];
-#endif
-        t |= ri.w[j] ^ twice;
-    }
-    return t & 0xfc00fc00u;
 }
 
 // What a lane's coefficient row contributes to the classification of its block (rle.rs:138-149): a non-zero value
@@ -944,7 +949,7 @@ H263_DEV RowClass recon_row_class(const RowIn &ri, int lane)
 // non-zero LEVEL in its last pair (kernels.hip: recon_round_rows decides it with one ballot).  Nothing of what the general
 // form spends on being general is left: no activity mask, no class, no column count -- dequantise 4 pairs, 8 terms, store.
 // The arithmetic is the general form's with n_cols = 8 and no first-column-only block: bit for bit the same results.
-// WIDE (round 5): some LEVEL of the round lies outside [-512, 511] (rowin_wide_bits): the dequantiser is the wrapping
+// WIDE (round 5): some LEVEL of the round lies outside [-512, 511] (RowIn::wide): the dequantiser is the wrapping
 // one (dequant_pair_wrap: the reference's i16 arithmetic as a release build executes it), the coefficients are not scaled
 // and the table is the basis itself.  Where nothing overflows both forms give the same bits (powers of two commute with
 // every rounding on the way), so WHICH rounds take this form is a matter of speed only.

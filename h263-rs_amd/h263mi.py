@@ -74,7 +74,7 @@ EXPORTS = [
     "h263mi_batch_submit_host", "h263mi_submit_picture_events", "h263mi_batch_submit_host_events",
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
-    "h263mi_synth_picture_host", "h263mi_synth_batch_device",
+    "h263mi_synth_picture_host", "h263mi_synth_batch_device", "h263mi_synth_batch_device_strided",
     "h263mi_render_rgba_pinned", "h263mi_host_alloc", "h263mi_host_free", "h263mi_host_register", "h263mi_host_unregister",
     "h263mi_debug_fail_nth_hip_call",
     "h263mi_mixed_create", "h263mi_mixed_destroy", "h263mi_mixed_decode_next_pictures", "h263mi_mixed_sync",
@@ -205,6 +205,8 @@ def lib():
         L.h263mi_synth_picture_host.argtypes = [i32, u16, u16, u32, u32, vp, vp, sz, C.POINTER(sz)]
         L.h263mi_synth_batch_device.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, vp, vp, sz, vp,
                                                 C.POINTER(sz)]
+        L.h263mi_synth_batch_device_strided.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, u32, vp, vp, sz, vp,
+                                                        C.POINTER(sz)]
         _lib = L
     return _lib
 
@@ -709,10 +711,11 @@ def synth_picture_host(kind, width, height, stream_id, frame_idx):
 
 
 def synth_batch_device(kind, width, height, n_streams, first_stream_id, frame_idx, d_mbs, d_coeffs, capacity_blocks,
-                       d_coeff_base, device_id=0, stream=None):
+                       d_coeff_base, device_id=0, stream=None, stream_stride=1):
+    """picture p of the batch is stream first_stream_id + p * stream_stride"""
     cfg = BackendCfg(device_id, 0, stream)
     total = C.c_size_t(0)
-    _check(lib().h263mi_synth_batch_device(C.byref(cfg), kind, width, height, n_streams, first_stream_id, frame_idx,
-                                           d_mbs, d_coeffs, capacity_blocks, d_coeff_base, C.byref(total)),
+    _check(lib().h263mi_synth_batch_device_strided(C.byref(cfg), kind, width, height, n_streams, first_stream_id, stream_stride,
+                                                   frame_idx, d_mbs, d_coeffs, capacity_blocks, d_coeff_base, C.byref(total)),
            "synth_batch_device")
     return total.value

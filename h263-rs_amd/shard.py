@@ -58,3 +58,36 @@ def aggregate_pictures(dist, pictures_this_rank):
     t = torch.tensor([pictures_this_rank], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def aggregate_rate(dist, units_this_rank, seconds_this_rank):
+    """Whole-job rate of a leg every rank ran on its own streams at the same time: units summed over the ranks divided
+    by the slowest rank's time (the end-to-end leg of bench.py: pictures per second of N host parsers + N GPUs)."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return units_this_rank / seconds_this_rank if seconds_this_rank > 0 else 0.0, int(units_this_rank), seconds_this_rank
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    u = torch.tensor([units_this_rank], dtype=torch.int64, device=dev)
+    t = torch.tensor([seconds_this_rank], dtype=torch.float64, device=dev)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    units, seconds = int(u.item()), float(t.item())
+    return (units / seconds if seconds > 0 else 0.0), units, seconds
+
+
+def local_world_size(world):
+    """ranks that share this node (and its CPU quota): LOCAL_WORLD_SIZE as torch.distributed.run exports it, else the
+    world size (bench.py runs on ONE node)"""
+    import os
+    try:
+        n = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
+    except ValueError:
+        n = 0
+    return max(1, n if n > 0 else world)
+
+
+def parser_threads_for_rank(cpu_budget, world):
+    """Host parser threads ONE rank may use: the CPUs this container may use (cgroup quota / affinity / physical cores:
+    bench.physical_cores) divided by the ranks that share them -- never "one per hardware thread per rank" (8 ranks x 256
+    threads on a 16-CPU quota only get throttled)."""
+    return max(1, int(cpu_budget) // local_world_size(world))

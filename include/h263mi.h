@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define H263MI_ABI_VERSION 4
+#define H263MI_ABI_VERSION 5
 
 /* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
 #define H263MI_OK                                  0
@@ -531,6 +531,12 @@ int h263mi_synth_batch_device(const h263mi_backend_cfg *cfg, int kind, uint16_t 
                               uint32_t n_streams, uint32_t first_stream_id, uint32_t frame_idx,
                               h263mi_mb_record *d_mbs, int16_t *d_coeffs, size_t coeff_capacity_blocks,
                               uint64_t *d_coeff_base, size_t *total_blocks);
+/* (ABI 5) ... stream ids first_stream_id, first_stream_id + stream_stride, ...: the streams ONE rank of a job owns when
+ * stream s of T is pinned to GPU s mod n_gpu (bench.py --total-streams). */
+int h263mi_synth_batch_device_strided(const h263mi_backend_cfg *cfg, int kind, uint16_t width, uint16_t height,
+                                      uint32_t n_streams, uint32_t first_stream_id, uint32_t stream_stride,
+                                      uint32_t frame_idx, h263mi_mb_record *d_mbs, int16_t *d_coeffs,
+                                      size_t coeff_capacity_blocks, uint64_t *d_coeff_base, size_t *total_blocks);
 
 #ifdef __cplusplus
 }

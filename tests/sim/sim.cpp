@@ -49,14 +49,20 @@ void sim_dequant_pairs_wrap(const uint32_t *levels, uint32_t n_pairs, uint32_t q
     for (uint32_t i = 0; i < n_pairs; i++) out[i] = dequant_pair_wrap(levels[i], two_q2, qmp2);
 }
 
-// the detector of LEVELs outside [-512, 511] (recon_kernel.inl: rowin_wide_bits) on n coefficient rows of 8 int16
+// the detector of LEVELs outside [-512, 511] (recon_kernel.inl: wide_bits_of) on n coefficient rows of 8 int16
 void sim_wide_bits(const uint32_t *rows, uint32_t n_rows, uint32_t *out)
 {
     for (uint32_t i = 0; i < n_rows; i++) {
-        RowIn ri{};
-        for (int j = 0; j < 4; j++) ri.w[j] = rows[4 * i + j];
-        out[i] = rowin_wide_bits(ri);
+        uint32_t t = 0;
+        for (int j = 0; j < 4; j++) t |= wide_bits_of(rows[4 * i + j]);
+        out[i] = t & WIDE_MASK_PAIR;
     }
+}
+
+// ... and on n event words (LEVEL << 16 | position)
+void sim_wide_bits_events(const uint32_t *events, uint32_t n, uint32_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = wide_bits_of(events[i]) & WIDE_MASK_EVENT;
 }
 
 // 1: every IDCT round of sim_recon takes the wide form (which rounds do is a matter of speed only: the results must not
@@ -153,7 +159,7 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
                         if (rc.beyond_first) cols_any |= 1ull << l;
                     }
                     bool wide = false;                                      // as kernels.hip: recon_round_rows
-                    for (int l = 0; l < 64; l++) wide = wide || rowin_wide_bits(ri[l]) != 0;
+                    for (int l = 0; l < 64; l++) wide = wide || ri[l].wide != 0;
                     if (force_wide_rounds) wide = true;
                     for (int l = 0; l < 64; l++) {
                         if (wide) recon_phase_idct_rows<false, true>(*s, ri[l], l, cols_from_mask(wm), cols_any);

@@ -10,7 +10,8 @@
     every int16 LEVEL at every quantiser;
  3. the kernel's wrapping dequantiser (recon_kernel.inl: dequant_pair_wrap, through tests/sim) must too, its fast form
     (dequant_pair_i16) must be 16 x the same value wherever |LEVEL| <= 511 -- the condition under which a round takes it --
-    and the detector of wider LEVELs (rowin_wide_bits) must fire exactly outside [-512, 511];
+    and the detector of wider LEVELs (wide_bits_of, on coefficient rows and on event words) must fire exactly outside
+    [-512, 511];
  4. whole pictures with 11-bit LEVELs at quantisers 16..31 through the sim's wave against the oracle, and: forcing
     EVERY round through the wide form changes nothing (which rounds take it is a matter of speed only).
 The MI355X side of this is tests/test_gpu_round5.py and the fourth mutant of tests/test_gpu_mutation.py.
@@ -127,6 +128,14 @@ def test_wide_level_detector_fires_exactly_outside_pm512():
         L.sim_wide_bits(rows.ctypes.data, 65536, got.ctypes.data)
         v = rows[:, pos].astype(np.int64)
         assert ((got != 0) == ((v < -512) | (v > 511))).all(), pos
+    # ... and on event words, LEVEL << 16 | position, every LEVEL with every position
+    L.sim_wide_bits_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lv = np.arange(-32768, 32768, dtype=np.int64)
+    for pos in (0, 1, 31, 62, 63):
+        ev = ((lv & 0xffff) << 16 | pos).astype(np.uint32)
+        got = np.empty(65536, np.uint32)
+        L.sim_wide_bits_events(ev.ctypes.data, 65536, got.ctypes.data)
+        assert ((got != 0) == ((lv < -512) | (lv > 511))).all(), pos
 
 
 @pytest.mark.parametrize("w,h,quant", [(176, 144, 31), (64, 48, 16), (100, 60, 17), (48, 32, 24)])
@@ -142,16 +151,20 @@ def test_pictures_with_11_bit_levels_at_large_quantisers(w, h, quant):
     nz = np.flatnonzero(flat)
     flat[nz[rng.random(nz.size) < 0.05]] = -1024          # the one LEVEL that wraps at q = 16
     rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
-    st, got = simlib.recon(w, h, mbs, coeffs, ref)
-    assert rc == 0 and st == 0
-    for g, e, name in zip(got, want, "Y Cb Cr".split()):
-        assert (g == e).all(), (name, np.flatnonzero(g != e)[:10])
+    assert rc == 0
+    for events in (False, True):
+        st, got = simlib.recon(w, h, mbs, coeffs, ref, events=events)
+        assert st == 0
+        for g, e, name in zip(got, want, "Y Cb Cr".split()):
+            assert (g == e).all(), (events, name, np.flatnonzero(g != e)[:10])
     mbs, coeffs = recgen.intra_picture(w, h, seed=quant, max_level=1023, quant=quant)
     rc, want = orc.decode_picture(w, h, mbs, coeffs, None)
-    st, got = simlib.recon(w, h, mbs, coeffs, None)
-    assert rc == 0 and st == 0
-    for g, e in zip(got, want):
-        assert (g == e).all()
+    assert rc == 0
+    for events in (False, True):
+        st, got = simlib.recon(w, h, mbs, coeffs, None, events=events)
+        assert st == 0
+        for g, e in zip(got, want):
+            assert (g == e).all()
 
 
 @pytest.mark.parametrize("max_level,quant", [(127, 10), (511, 31), (1023, 31)])

@@ -31,6 +31,9 @@ done
 # at 64 bytes, times 2 is exact; TCC_EA0_RDREQ_DRAM_32B x 32 bytes agrees to 0.2 %)
 timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv -d $OUT/pmc_RDREQ -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_RDREQ.log
 timeout 600 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum --output-format csv -d $OUT/pmc_WRREQ -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_WRREQ.log
+# ... and what the vector ALUs did (round 5: the launch is bound by their issue slots, bench.py reports it as roofline.valu)
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_VALU -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_VALU.log
+timeout 600 rocprofv3 --pmc VALUBusy --output-format csv -d $OUT/pmc_VALUBUSY -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/pmc_VALUBUSY.log
 cd $R
 python3 - "$OUT" "$TAG" "$STAMP" <<'PY'
 import csv, glob, json, os, sys, collections
@@ -38,7 +41,7 @@ sys.path.insert(0, os.getcwd())
 import bench
 out, tag, stamp = sys.argv[1], sys.argv[2], sys.argv[3]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for c in ("FETCH_SIZE", "WRITE_SIZE", "RDREQ", "WRREQ"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "RDREQ", "WRREQ", "VALU", "VALUBUSY"):
     for path in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
         rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r.get("Dispatch_Id", 0)))
         for row in rows:
@@ -73,7 +76,17 @@ for k, v in acc.items():
             "write_requests": int(wr or 0), "of_which_64_bytes": int(wr64 or 0), "write_bytes_dram_32B_units": int(32 * (wr_dram or 0)),
             "what": "TCC_EA0_* request counters of the same command: reads are 128-byte requests (FETCH_SIZE prices them at 64: "
                     "the x2), the DRAM counters are in 32-byte units"}
-json.dump({"tag": tag, "box": stamp, "kernel_source_hash": bench.kernel_source_hash(),
+valu = {}
+for k, v in acc.items():
+    if v.get("SQ_INSTS_VALU") and v.get("VALUBusy"):
+        m = lambda name: sum(v[name]) / len(v[name])
+        valu[k] = {"insts_per_launch": int(m("SQ_INSTS_VALU")), "busy_frac": round(m("VALUBusy") / 100.0, 4),
+                   "gui_active_cycles": int(m("GRBM_GUI_ACTIVE")) if v.get("GRBM_GUI_ACTIVE") else None,
+                   "launches_sampled": len(v["SQ_INSTS_VALU"]),
+                   "what": "means over every launch of the profiled GOPs (I and P pictures in the bench's mix): SQ_INSTS_VALU = "
+                           "vector instructions issued (wave64: x 64 lane operations), VALUBusy = share of the launch's cycles the "
+                           "vector ALUs were busy"}
+json.dump({"tag": tag, "box": stamp, "kernel_source_hash": bench.kernel_source_hash(), "valu": valu,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --gops-per-step 1 --steps 2 "
                    "--warmup 1` (93 launches per kernel: 3 I + 90 P pictures x 64 streams); FETCH_SIZE x2 (gfx950: every L2 read "
                    "request is 128 bytes and FETCH_SIZE prices it at 64 -- checked on k_frame's own access shapes, 12-byte gathers "

@@ -201,6 +201,70 @@ H263MI_TABLE(mcbpc_p_table, kMcbpcPCodes)
 H263MI_TABLE(cbpy_table, kCbpyCodes)
 H263MI_TABLE(mvd_table, kMvdCodes)
 
+// ---- combined look-ups for the macroblock header windows (round 5) -----------------------------------------------
+// The header of a coded macroblock is a chain of code words whose positions depend on each other: MCBPC, then CBPY, then
+// (DQUANT and) the vector difference pairs -- one dependent table access after the other (25 ns per inter macroblock, half
+// of the parse time of a real P picture: profiles/r04_q_parser_stage_costs.txt).  Two tables made of the code tables above
+// take two links out of the chain, for the short code words that make up nearly all of a real stream; everything they do
+// not resolve (entry 0) goes the way of the single code tables, which is the definition of the behaviour
+// (macroblock.rs:445-549):
+//   header12[12 bits behind COD]   MCBPC + CBPY when both lie inside 12 bits: len | type << 4 | coded6 << 7 (coded6: bit
+//                                  5 - b = block b, CBPY already in the sense of the macroblock's kind, macroblock.rs:479-489)
+//   mvd_pair10[10 bits]            a horizontal and a vertical MVD code word (Table 14) that lie inside 10 bits together:
+//                                  len | (dx & 63) << 4 | (dy & 63) << 10 -- the small differences of slow motion
+namespace {
+constexpr uint32_t kEventLast = 1u << 4, kEventEscape = 1u << 5, kEventInvalid = 1u << 6;
+struct HeaderTables {
+    uint16_t p12[4096], i12[4096], mvd10[1024];
+    // tcoef13[13 bits]: EVERY TCOEF code word (12 bits at most, Table 16/H.263) together with its sign bit, as the event it
+    // stands for: used (code + sign, 3..13) | last << 4 | run << 8 | level (signed) << 16.  ESCAPE ("0000 011") is
+    // kEventEscape, a prefix no code word starts with kEventInvalid (both with used = 0).  32 KB; what a stream touches of it
+    // are the blocks of its frequent short code words.
+    uint32_t tcoef13[8192];
+    HeaderTables()
+    {
+        for (uint32_t idx = 0; idx < 8192; idx++) {
+            const VlcTable::Slot &t = tcoef_table().lookup32(idx << 19);
+            if (!t.valid) { tcoef13[idx] = kEventInvalid; continue; }
+            if (t.v0 < 0) { tcoef13[idx] = kEventEscape; continue; }
+            const uint32_t sign = (idx >> (12 - t.len)) & 1u;
+            const int level = sign ? -(int)t.v2 : (int)t.v2;
+            tcoef13[idx] = (uint32_t)(t.len + 1) | ((uint32_t)(t.v0 != 0) << 4) | ((uint32_t)t.v1 << 8) | ((uint32_t)(uint16_t)(int16_t)level << 16);
+        }
+        for (int pic = 0; pic < 2; pic++) {
+            const VlcTable &mc = pic ? mcbpc_i_table() : mcbpc_p_table();
+            uint16_t *out = pic ? i12 : p12;
+            for (uint32_t idx = 0; idx < 4096; idx++) {
+                out[idx] = 0;
+                const uint32_t w = idx << 20;
+                const VlcTable::Slot &m = mc.lookup32(w);
+                if (!m.valid || m.v0 < 0 || m.len > 12) continue;           // invalid or stuffing: the ordinary way
+                const VlcTable::Slot &c = cbpy_table().lookup32(w << m.len);
+                if (!c.valid || m.len + c.len > 12) continue;
+                const bool intra = m.v0 == H263MI_MB_INTRA || m.v0 == H263MI_MB_INTRA_Q;
+                const uint32_t luma = intra ? (uint32_t)c.v0 : (~(uint32_t)c.v0 & 0xfu);
+                const uint32_t coded6 = (luma << 2) | ((uint32_t)m.v1 << 1) | (uint32_t)m.v2;
+                out[idx] = (uint16_t)((uint32_t)(m.len + c.len) | ((uint32_t)m.v0 << 4) | (coded6 << 7));
+            }
+        }
+        for (uint32_t idx = 0; idx < 1024; idx++) {
+            mvd10[idx] = 0;
+            const uint32_t w = idx << 22;
+            const VlcTable::Slot &x = mvd_table().lookup32(w);
+            if (!x.valid || x.len > 10) continue;
+            const VlcTable::Slot &y = mvd_table().lookup32(w << x.len);
+            if (!y.valid || x.len + y.len > 10) continue;
+            mvd10[idx] = (uint16_t)((uint32_t)(x.len + y.len) | (((uint32_t)x.v0 & 63u) << 4) | (((uint32_t)y.v0 & 63u) << 10));
+        }
+    }
+};
+const HeaderTables &header_tables()
+{
+    static const HeaderTables t;
+    return t;
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------
 // block layer: parser/block.rs:670-755
 // ---------------------------------------------------------------------------------------------------
@@ -214,20 +278,21 @@ inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra,
     const size_t checkpoint = r.position();
     int rc = H263MI_OK;
     do {
+        const VlcTable &table = tcoef_table();
+        const bool sorenson_v1 = sorenson && version == 1;   // Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL
+        // (the cursor of the fast path lives in a local: the reader object is shared with code the compiler cannot see
+        // through, and a load + store of its position per event was a quarter of the time of a dense picture)
+        size_t pos = checkpoint;
+        const size_t end32 = r.size_bits() >= 32 ? r.size_bits() - 32 : 0;
+        const bool have32 = r.size_bits() >= 32 && !field_by_field;
+        uint32_t esc_streak = 0;
         if (intra) {
             uint32_t code;
             if ((rc = r.read_u8(code)) != H263MI_OK) break;
             if (code == 0 || code == 128) { rc = H263MI_ERR_INVALID_INTRA_DC; break; }   // IntraDc::from_u8, types.rs:930-936
             intradc = (uint8_t)code;
+            pos = r.position();
         }
-        const VlcTable &table = tcoef_table();
-        const bool sorenson_v1 = sorenson && version == 1;   // Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL
-        // (the cursor of the fast path lives in a local: the reader object is shared with code the compiler cannot see
-        // through, and a load + store of its position per event was a quarter of the time of a dense picture)
-        size_t pos = r.position();
-        const size_t end32 = r.size_bits() >= 32 ? r.size_bits() - 32 : 0;
-        const bool have32 = r.size_bits() >= 32 && !field_by_field;
-        uint32_t esc_streak = 0;
         while (tcoef_present) {
             if (have32 && pos <= end32) {
                 // Fast path: the longest TCOEF event -- escape (7) + Sorenson width flag + LAST + RUN (6) + LEVEL (11)
@@ -316,6 +381,211 @@ inline int decode_block_to(BitReader &r, bool sorenson, int version, bool intra,
     } while (0);
     if (rc != H263MI_OK) r.rollback(checkpoint);
     return rc;
+}
+}  // namespace
+
+// ---- the TCOEF events of one block, as a function of its own (round 5) ----------------------------------------------------
+// parse_picture is one very large function: inlined into it, the event loop above keeps its own state (zigzag position, event
+// count, the output pointer, the overrun flag) in stack slots -- a load, an add and a store of the zigzag position per event,
+// a reload of the output pointer per event -- because sixteen registers do not hold the loop's values and the macroblock
+// loop's around it.  Here the loop has the registers to itself: it takes what it needs by value and hands back where it
+// stopped.  It runs while a whole 64-bit window of data lies behind the cursor (pos <= end64: every event, 26 bits at most,
+// is wholly inside the data, and the 8-byte load is inside the buffer); the last bytes of a picture, and everything
+// irregular, are left to decode_block_to, which continues from the returned state.  Same bits, same events, same errors
+// (tests/test_parser_paths.py and the fuzzer hold the two forms against each other).
+namespace {
+struct BlockRun {
+    size_t pos;            // bit position behind the last event taken
+    uint32_t zz;           // next zigzag index
+    uint32_t n_ev;         // events stored
+    int rc;                // H263MI_OK, or the error of the event at `pos`
+    bool more;             // no LAST yet: the caller goes on from pos
+    bool overrun;          // a run walked past zigzag 63 (rle.rs:125-127): the block is void, the rest was parsed and dropped
+};
+
+template <bool SORENSON_V1>
+__attribute__((noinline)) BlockRun block_events_fast(const uint8_t *base, size_t pos, size_t end64, uint32_t zz, uint32_t *ev,
+                                                     const VlcTable &table)
+{
+    uint32_t n_ev = 0, esc_streak = 0;
+    bool overrun = false, more = true;
+    int rc = H263MI_OK;
+    while (more && pos <= end64) {
+        uint64_t v;
+        __builtin_memcpy(&v, base + (pos >> 3), 8);
+        const uint32_t w = (uint32_t)((__builtin_bswap64(v) << (pos & 7)) >> 32);
+        uint32_t used, run;
+        int level;
+        bool last;
+        if (esc_streak >= 2 && (w >> 25) == 3u) {            // a run of ESCAPEs: fixed field positions, no table access
+            const uint32_t flagbit = (w >> 24) & 1u;
+            const uint32_t width = SORENSON_V1 ? 7u + 4u * flagbit : 8u;
+            const uint32_t e0 = SORENSON_V1 ? 8u : 7u;
+            const uint32_t raw = (w >> (25 - e0 - width)) & ((1u << width) - 1u);
+            level = (int)((raw ^ (1u << (width - 1))) - (1u << (width - 1)));
+            used = e0 + 7u + width;
+            run = (w >> (25 - e0)) & 63u;
+            last = ((w >> (31 - e0)) & 1u) != 0;
+        } else {
+            const VlcTable::Slot &sl = table.lookup32(w);
+            const uint32_t len = sl.len;
+            if (!sl.valid) { rc = H263MI_ERR_INVALID_SHORT_COEFFICIENT; break; }
+            // both readings of the window, one selected by mask (short code + sign against ESCAPE, block.rs:689-724)
+            const uint32_t esc = sl.v0 < 0 ? ~0u : 0u;
+            const uint32_t sign = (w >> (31 - len)) & 1u;
+            const uint32_t short_level = ((uint32_t)sl.v2 ^ (0u - sign)) + sign;
+            const uint32_t flag = SORENSON_V1 ? 1u : 0u;
+            const uint32_t width = SORENSON_V1 ? 7u + 4u * sign : 8u;
+            const uint32_t e0 = len + flag;
+            const uint32_t esc_last = (w >> (31 - e0)) & 1u;
+            const uint32_t esc_run = (w >> (25 - e0)) & 63u;
+            const uint32_t raw = (w >> (25 - e0 - width)) & ((1u << width) - 1u);
+            const uint32_t esc_level = (raw ^ (1u << (width - 1))) - (1u << (width - 1));
+            used = ((e0 + 7u + width) & esc) | ((len + 1u) & ~esc);
+            level = (int)((esc_level & esc) | (short_level & ~esc));
+            run = (esc_run & esc) | ((uint32_t)sl.v1 & ~esc);
+            last = ((esc_last & esc) | ((uint32_t)(sl.v0 != 0) & ~esc)) != 0;
+            esc_streak = (esc_streak + 1u) & esc;
+        }
+        if (level == 0) { rc = H263MI_ERR_INVALID_LONG_COEFFICIENT; break; }     // only an ESCAPE can say 0
+        pos += used;
+        more = !last;
+        if (overrun) continue;
+        zz += run;
+        if (zz >= 64) { overrun = true; continue; }
+        ev[n_ev++] = ((uint32_t)(uint16_t)(int16_t)level << 16) | kZigzagRaster[zz++];
+    }
+    return BlockRun{pos, zz, n_ev, rc, more, overrun};
+}
+
+// ---- one event out of the bits at the cursor, without a branch on what kind of event it is --------------------------------
+// `bits`: the unread bits at the top of a 64-bit word (30 of them, at least, are data).  A short code word + sign is one
+// access to the 13-bit table of ready-made events (HeaderTables::tcoef13).  An ESCAPE (block.rs:689-724) has its fields at
+// FIXED places behind the 7-bit code word -- [Sorenson v1: 1 bit that selects an 11- or 7-bit LEVEL] LAST, RUN (6), LEVEL --
+// so that reading is computed from the bits beside the table access, whatever the table says, and a mask picks one of the
+// two.  (Real key frames are a quarter ESCAPEs, a third code words of nine bits and more: a branch on either kind is a coin
+// toss, and round 4's form -- both readings computed from the table's LENGTH -- spent seventy instructions per event.)
+// Returns the event in the table's format (kEventInvalid set: no code word starts here) and the bits it takes in `used`.
+template <bool SORENSON_V1>
+inline __attribute__((always_inline)) uint32_t event_at(uint64_t bits, const uint32_t *tcoef13, uint32_t &used)
+{
+    const uint32_t e = tcoef13[bits >> 51];
+    const uint32_t w = (uint32_t)(bits >> 32);
+    const uint32_t e0 = SORENSON_V1 ? 8u : 7u;                                   // position of LAST
+    const uint32_t width = SORENSON_V1 ? 7u + 4u * ((w >> 24) & 1u) : 8u;
+    const uint32_t raw = (w >> (25u - e0 - width)) & ((1u << width) - 1u);
+    const uint32_t level = (raw ^ (1u << (width - 1u))) - (1u << (width - 1u));   // two's complement of `width` bits (reader.rs:176-187)
+    const uint32_t esc_event = (((w >> (31u - e0)) & 1u) << 4) | (((w >> (25u - e0)) & 63u) << 8) | (level << 16) | kEventEscape;
+    const uint32_t m = 0u - ((e >> 5) & 1u);                                     // all ones for an ESCAPE
+    used = ((e0 + 7u + width) & m) | (e & 15u & ~m);
+    return (esc_event & m) | (e & ~m);
+}
+
+// ALL coded blocks of one INTER macroblock in one loop.  An inter block is nothing but its events (no INTRADC in front,
+// block.rs:682-687), so the blocks of a macroblock follow each other in the bitstream like one long list with LAST marks in
+// it.  Taken block by block, every block ends in a loop exit no predictor can learn (a block has two or three events, or one,
+// or seven) and the macroblock in another (it has one coded block, or none, or three): about two mispredicted branches per
+// macroblock, a third of the parse time of a real P picture.  Here a LAST event ends a block WITHOUT a branch -- the block's
+// offset word is written behind every event and the write position moves on by `last`, the zigzag position is reset by a
+// conditional move -- and the one branch that depends on the data is "was that the macroblock's last block".
+// The bits come out of a register that is refilled beside the decode (an unaligned 8-byte load OR-ed in below the valid
+// bits; stream position of the next unread bit = 8 * (ptr - base) - cnt), so that the loop-carried chain is table -> length
+// -> shift.
+// Hands back `done` = false (nothing of what it wrote counts) for everything out of the ordinary: the data ends inside the
+// macroblock, a run walks past zigzag 63; the caller then takes the macroblock block by block from where it began.
+struct InterRun {
+    size_t pos;
+    uint32_t n_ev;
+    int rc;
+    bool done;
+};
+inline uint64_t be64_at(const uint8_t *q)
+{
+    uint64_t x;
+    __builtin_memcpy(&x, q, 8);
+    return __builtin_bswap64(x);
+}
+template <bool SORENSON_V1>
+__attribute__((noinline)) InterRun inter_macroblock_events(const uint8_t *base, size_t pos, size_t end64, uint32_t remaining, uint32_t *ev,
+                                                           uint32_t *fe, uint32_t events_before, const uint32_t *tcoef13)
+{
+    if (pos > end64) return InterRun{pos, 0, H263MI_OK, false};
+    // (pos <= end64: 8 bytes at pos >> 3 are inside the data; `safe` = the last place an 8-byte load may start)
+    const uint8_t *const safe = base + (end64 >> 3);
+    const uint8_t *ptr = base + (pos >> 3) + 7;
+    uint64_t bits = be64_at(ptr - 7) << (pos & 7);
+    uint32_t cnt = 56u - (uint32_t)(pos & 7);                // (the byte at `ptr` is in `bits` already, unaccounted)
+    uint32_t *out = ev;
+    uint32_t zz = 0;
+    for (;;) {
+        if (__builtin_expect(ptr > safe, 0)) return InterRun{pos, 0, H263MI_OK, false};
+        uint32_t used;
+        const uint32_t e = event_at<SORENSON_V1>(bits, tcoef13, used);          // at least 30 bits of `bits` are accounted for here
+        bits |= be64_at(ptr) >> cnt; ptr += (63u - cnt) >> 3; cnt |= 56u;       // refill
+        if (__builtin_expect((e & kEventInvalid) != 0, 0)) return InterRun{pos, 0, H263MI_ERR_INVALID_SHORT_COEFFICIENT, false};
+        if (__builtin_expect((e >> 16) == 0, 0)) return InterRun{pos, 0, H263MI_ERR_INVALID_LONG_COEFFICIENT, false};   // only an ESCAPE can say 0
+        bits <<= used; cnt -= used;
+        zz += (e >> 8) & 63u;
+        if (__builtin_expect(zz >= 64, 0)) return InterRun{pos, 0, H263MI_OK, false};          // rle.rs:125-127: block by block
+        *out++ = (e & 0xffff0000u) | kZigzagRaster[zz];
+        const uint32_t last = (e >> 4) & 1u;
+        fe[1] = events_before + (uint32_t)(out - ev);       // the block's end (rewritten until its LAST event)
+        fe += last;
+        zz = last ? 0u : zz + 1u;
+        remaining -= last;
+        if (remaining == 0) break;
+    }
+    return InterRun{(size_t)(ptr - base) * 8 - cnt, (uint32_t)(out - ev), H263MI_OK, true};
+}
+
+// The six blocks of one INTRA macroblock as ONE list of items.  A block is an INTRADC code (8 bits, block.rs:682-686) and,
+// when it is coded, events up to a LAST mark; block after block that is "DC, event, event, DC, DC, event, DC, ..." -- and taken
+// block by block every "is it coded" and every "was that the last event" is a branch on fresh data (a key frame: 49 000
+// blocks of one or two events).  Here an iteration takes ONE item, whichever kind it is: both readings of the bits at the
+// cursor are at hand (the top byte as an INTRADC code, the event of event_at) and the iteration's bookkeeping -- bits
+// consumed, where the output goes, whether the block ends, the zigzag position -- is selected by the item's kind with
+// conditional moves.  The one branch that depends on the data is the end of the macroblock.  `done` = false as above.
+template <bool SORENSON_V1>
+__attribute__((noinline)) InterRun intra_macroblock_events(const uint8_t *base, size_t pos, size_t end64, uint32_t coded6, uint32_t *ev,
+                                                           uint32_t *fe, uint32_t events_before, const uint32_t *tcoef13, uint8_t *dc_out)
+{
+    if (pos > end64) return InterRun{pos, 0, H263MI_OK, false};
+    const uint8_t *const safe = base + (end64 >> 3);
+    const uint8_t *ptr = base + (pos >> 3) + 7;
+    uint64_t bits = be64_at(ptr - 7) << (pos & 7);
+    uint32_t cnt = 56u - (uint32_t)(pos & 7);
+    uint32_t *out = ev;
+    uint32_t b = 0, is_dc = 1, zz = 1;
+    uint8_t dcs[16];                                         // [0..5] the codes, [8..13] where the write of an event item lands
+    for (;;) {
+        if (__builtin_expect(ptr > safe, 0)) return InterRun{pos, 0, H263MI_OK, false};
+        const uint32_t top = (uint32_t)(bits >> 56);
+        uint32_t ev_used;
+        const uint32_t e = event_at<SORENSON_V1>(bits, tcoef13, ev_used);
+        bits |= be64_at(ptr) >> cnt; ptr += (63u - cnt) >> 3; cnt |= 56u;       // refill
+        const uint32_t is_ev = is_dc ^ 1u;
+        if (__builtin_expect(is_dc & (uint32_t)(top == 0 || top == 128), 0)) return InterRun{pos, 0, H263MI_ERR_INVALID_INTRA_DC, false};   // types.rs:930-936
+        if (__builtin_expect(is_ev & (uint32_t)((e & kEventInvalid) != 0), 0)) return InterRun{pos, 0, H263MI_ERR_INVALID_SHORT_COEFFICIENT, false};
+        if (__builtin_expect(is_ev & (uint32_t)((e >> 16) == 0), 0)) return InterRun{pos, 0, H263MI_ERR_INVALID_LONG_COEFFICIENT, false};
+        const uint32_t used = is_dc ? 8u : ev_used;
+        bits <<= used; cnt -= used;
+        dcs[b + 8u * is_ev] = (uint8_t)top;
+        const uint32_t zz_next = zz + ((e >> 8) & 63u);
+        if (__builtin_expect(is_ev & (uint32_t)(zz_next >= 64), 0)) return InterRun{pos, 0, H263MI_OK, false};             // rle.rs:125-127
+        *out = (e & 0xffff0000u) | kZigzagRaster[zz_next & 63u];
+        out += is_ev;
+        const uint32_t ev_last = is_ev & (e >> 4);                          // this event ends its block
+        const uint32_t coded_b = (coded6 >> (5u - b)) & 1u;
+        const uint32_t fin = is_dc ? (coded_b ^ 1u) : ev_last;             // this item ends its block
+        fe[1] = events_before + (uint32_t)(out - ev);                        // the block's end (rewritten until its LAST event)
+        fe += ev_last;
+        zz = is_dc ? 1u : zz_next + 1u;                                      // the TCOEFs of an intra block start at zigzag 1 (rle.rs:117-121)
+        b += fin;
+        is_dc = fin;
+        if (b == 6) break;
+    }
+    for (int k = 0; k < 6; k++) dc_out[k] = dcs[k];
+    return InterRun{(size_t)(ptr - base) * 8 - cnt, (uint32_t)(out - ev), H263MI_OK, true};
 }
 }  // namespace
 
@@ -829,8 +1099,15 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     const bool window_header = (is_i || is_p) && !umv_vectors && !(running_options & OPT_MODIFIED_QUANTIZATION) && !out.field_by_field;
     const VlcTable &t_mcbpc = is_i ? t_mcbpc_i : t_mcbpc_p;
     static const int kDquant[4] = {-1, -2, 1, 2};
+    const HeaderTables &ht = header_tables();
+    // blocks out of 64-bit windows (block_events_fast): the product's configuration -- events only, no dense blocks
+    const bool fast_blocks = !want_dense && !out.field_by_field && r.size_bits() >= 64;
+    const size_t end64 = r.size_bits() >= 64 ? r.size_bits() - 64 : 0;
+    const bool sorenson_v1 = sorenson && hdr.version == 1;
+    const VlcTable &t_tcoef = tcoef_table();
+    const uint16_t *const header12 = is_i ? ht.i12 : ht.p12;
     for (;;) {                                       // state.rs:193-417
-        const size_t mb_checkpoint = r.position();   // decode_macroblock runs in a transaction (macroblock.rs:454)
+        size_t mb_checkpoint = r.position();         // decode_macroblock runs in a transaction (macroblock.rs:454)
         int mrc = H263MI_OK;
         bool stuffing = false, uncoded = false;
         int mb_type = 0, cb = 0, cr = 0, luma = 0, dquant = 0;
@@ -838,9 +1115,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         Mv mvd[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         bool have_header = false, run_taken = false;
         if (window_header && r.remaining() >= 64) do {
-            const size_t avail = r.remaining();
+            size_t avail = r.remaining();
             uint64_t w = r.peek_window();
             uint32_t used = 0, total_used = 0;       // bits taken from this window / from earlier windows
+            uint32_t shifted = 0;                    // bits the window has been shifted by already (a run of COD = 1 in front)
             const auto top32 = [&]() { return (uint32_t)((w << used) >> 32); };
             if (is_p) {
                 used = 1;
@@ -852,32 +1130,59 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                     const size_t room = total > n_mbs ? total - n_mbs : 0;
                     size_t run = (size_t)__builtin_clzll(~w | 1ull);           // leading ones, 1..63
                     if (run > room) run = room;
-                    if (run >= 2) {
-                        h263mi_mb_record skipped{};
-                        skipped.mb_type = H263MI_MB_INTER;
-                        skipped.quant = (uint8_t)(in_force_quantizer < 1 ? 1 : in_force_quantizer);
+                    if (run == 0) { uncoded = true; r.advance(1); have_header = true; break; }   // (no room: reported below)
+                    h263mi_mb_record skipped{};
+                    skipped.mb_type = H263MI_MB_INTER;
+                    skipped.quant = (uint8_t)(in_force_quantizer < 1 ? 1 : in_force_quantizer);
+                    if (n_mbs + 4 <= total) {
+                        // four records whatever the run (what lies beyond it is written again by its own macroblock): short
+                        // runs -- most of them -- then store without a loop whose trip count depends on the data
+                        for (size_t k = 0; k < 4; k++) recs[n_mbs + k] = skipped;
+                        memset(pv + n_mbs * 4, 0, 4 * 4 * sizeof(Mv));
+                        if (run > 4) {
+                            for (size_t k = 4; k < run; k++) recs[n_mbs + k] = skipped;
+                            memset(pv + (n_mbs + 4) * 4, 0, (run - 4) * 4 * sizeof(Mv));
+                        }
+                    } else {
                         for (size_t k = 0; k < run; k++) recs[n_mbs + k] = skipped;
                         memset(pv + n_mbs * 4, 0, run * 4 * sizeof(Mv));
-                        n_mbs += run;
-                        mb_col += run;
-                        while (mb_col >= mb_per_line) { mb_col -= mb_per_line; mb_line++; }
-                        r.advance((uint32_t)run);
-                        run_taken = true;
-                        break;
                     }
-                    uncoded = true; r.advance(1); have_header = true; break;
+                    n_mbs += run;
+                    mb_col += run;
+                    while (mb_col >= mb_per_line) { mb_col -= mb_per_line; mb_line++; }
+                    r.advance((uint32_t)run);
+                    // The run ends in front of a coded macroblock (a zero bit) unless the window or the picture cut it short:
+                    // that macroblock's header is taken out of the same window right away -- one trip through the loop, and one
+                    // data-dependent branch, for "some macroblocks that are not coded, then one that is" (round 4 took two).
+                    // Enough of the window must be left for COD + MCBPC + CBPY + DQUANT (15 bits) and a vector pair (26).
+                    if (run > 57 - 41 || n_mbs >= total || r.remaining() < 64) { run_taken = true; break; }
+                    w <<= run;
+                    if (w >> 63) { run_taken = true; break; }
+                    shifted = (uint32_t)run;
+                    avail -= run;
+                    mb_checkpoint = r.position();                              // the coded macroblock's own transaction
                 }
             }
-            const VlcTable::Slot &m = t_mcbpc.lookup32(top32());
-            if (!m.valid) break;
-            used += m.len;
-            if (m.v0 < 0) { stuffing = true; r.advance(used); have_header = true; break; }
-            mb_type = m.v0; cb = m.v1; cr = m.v2;
-            const bool intra = mb_type == H263MI_MB_INTRA || mb_type == H263MI_MB_INTRA_Q;
-            const VlcTable::Slot &c = t_cbpy.lookup32(top32());
-            if (!c.valid) break;
-            used += c.len;
-            luma = intra ? c.v0 : (~c.v0 & 0xf);                         // macroblock.rs:479-489
+            bool intra;
+            if (const uint32_t e = header12[(uint32_t)((w << used) >> 52)]) {
+                // MCBPC and CBPY in one access (the short code words: nearly every macroblock of a real stream)
+                used += e & 15u;
+                mb_type = (int)((e >> 4) & 7u);
+                const uint32_t coded6 = e >> 7;
+                luma = (int)(coded6 >> 2); cb = (int)((coded6 >> 1) & 1u); cr = (int)(coded6 & 1u);
+                intra = mb_type == H263MI_MB_INTRA || mb_type == H263MI_MB_INTRA_Q;
+            } else {
+                const VlcTable::Slot &m = t_mcbpc.lookup32(top32());
+                if (!m.valid) break;
+                used += m.len;
+                if (m.v0 < 0) { stuffing = true; r.advance(used); have_header = true; break; }
+                mb_type = m.v0; cb = m.v1; cr = m.v2;
+                intra = mb_type == H263MI_MB_INTRA || mb_type == H263MI_MB_INTRA_Q;
+                const VlcTable::Slot &c = t_cbpy.lookup32(top32());
+                if (!c.valid) break;
+                used += c.len;
+                luma = intra ? c.v0 : (~c.v0 & 0xf);                     // macroblock.rs:479-489
+            }
             if (mb_type == H263MI_MB_INTER_Q || mb_type == H263MI_MB_INTRA_Q || mb_type == H263MI_MB_INTER4V_Q) {
                 dquant = kDquant[(w << used) >> 62];                     // decode_dquant (macroblock.rs:257-271)
                 used += 2;
@@ -887,12 +1192,19 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             if (!intra) {
                 const int n_mv = (mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q) ? 4 : 1;
                 for (int k = 0; k < n_mv; k++) {
-                    if (used > 57 - 26) {            // not enough of the window left for two more code words
+                    if (used + shifted > 57 - 26) {  // not enough of the window left for two more code words
                         if (total_used + used > avail) { ok = false; break; }
                         r.advance(used);
                         total_used += used;
                         used = 0;
+                        shifted = 0;
                         w = r.peek_window();
+                    }
+                    if (const uint32_t e = ht.mvd10[(uint32_t)((w << used) >> 54)]) {
+                        // both code words of the pair in one access (small differences: slow motion, good prediction)
+                        used += e & 15u;
+                        mvd[k] = Mv{(int16_t)((int32_t)(e << 22) >> 26), (int16_t)((int32_t)(e << 16) >> 26)};
+                        continue;
                     }
                     const VlcTable::Slot &sx = t_mvd.lookup32(top32());  // decode_motion_vector (macroblock.rs:414-438)
                     used += sx.len;
@@ -1004,7 +1316,51 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             const uint32_t coded6 = ((uint32_t)luma << 2) | ((uint32_t)cb << 1) | (uint32_t)cr;   // bit 5 - b: block b
             // state.rs:287-381: the six blocks in order; an inter block without TCOEFs has no bits at all (block.rs:
             // 684-687), so an inter macroblock only visits its coded blocks (no branch per absent block)
-            for (uint32_t todo = intra ? 0x3fu : coded6; todo;) {
+            uint32_t todo = intra ? 0x3fu : coded6;
+            // coded6 (bit 5 - b = block b, the order of the bitstream) -> the record's cbp (bit b)
+            static const uint8_t kCbpOfCoded6[64] = {
+#define C6(v) (uint8_t)((((v) >> 5) & 1) | ((((v) >> 4) & 1) << 1) | ((((v) >> 3) & 1) << 2) | ((((v) >> 2) & 1) << 3) | ((((v) >> 1) & 1) << 4) | (((v) & 1) << 5))
+#define C6x8(v) C6(v), C6(v + 1), C6(v + 2), C6(v + 3), C6(v + 4), C6(v + 5), C6(v + 6), C6(v + 7)
+                C6x8(0), C6x8(8), C6x8(16), C6x8(24), C6x8(32), C6x8(40), C6x8(48), C6x8(56)
+#undef C6x8
+#undef C6
+            };
+            if (!intra && coded6 && fast_blocks) {
+                // every coded block of an inter macroblock in one loop (inter_macroblock_events)
+                const uint32_t n_coded = (uint32_t)__builtin_popcount(coded6);
+                const InterRun ir = sorenson_v1
+                    ? inter_macroblock_events<true>(r.data(), r.position(), end64, n_coded, out.events.data() + n_events,
+                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13)
+                    : inter_macroblock_events<false>(r.data(), r.position(), end64, n_coded, out.events.data() + n_events,
+                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13);
+                if (ir.rc != H263MI_OK) return finish(ir.rc);
+                if (ir.done) {
+                    r.rollback(ir.pos);
+                    rec.cbp = kCbpOfCoded6[coded6];
+                    n_events += ir.n_ev;
+                    n_blocks += n_coded;
+                    todo = 0;
+                }
+            }
+            if (intra && fast_blocks) {
+                // the six blocks of an intra macroblock as one list of items (intra_macroblock_events)
+                uint8_t dcs[8];
+                const InterRun ir = sorenson_v1
+                    ? intra_macroblock_events<true>(r.data(), r.position(), end64, coded6, out.events.data() + n_events,
+                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13, dcs)
+                    : intra_macroblock_events<false>(r.data(), r.position(), end64, coded6, out.events.data() + n_events,
+                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13, dcs);
+                if (ir.rc != H263MI_OK) return finish(ir.rc);
+                if (ir.done) {
+                    r.rollback(ir.pos);
+                    rec.cbp = kCbpOfCoded6[coded6];
+                    for (int b = 0; b < 6; b++) rec.intradc[b] = dcs[b];
+                    n_events += ir.n_ev;
+                    n_blocks += (uint32_t)__builtin_popcount(coded6);
+                    todo = 0;
+                }
+            }
+            while (todo) {
                 const int b = __builtin_clz(todo) - 26;                        // bit 5 - b, highest first
                 todo &= ~(0x20u >> b);
                 const bool coded = (coded6 >> (5 - b)) & 1u;
@@ -1020,7 +1376,27 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 size_t zz = intra ? 1 : 0, n_ev = 0;
                 bool overrun = false;
                 uint8_t dc = 0;
-                rc = decode_block_to(r, sorenson, hdr.version, intra, coded, dc, [&](bool, int run, int level) {
+                bool dc_taken = false, tcoef_left = coded;
+                if (fast_blocks) {
+                    // INTRADC and the events out of 64-bit windows while whole windows lie behind the cursor (block_events_fast)
+                    size_t bpos = r.position();
+                    if (intra && bpos <= end64) {
+                        const uint32_t code = (uint32_t)(r.window_at(bpos) >> 56);
+                        if (code == 0 || code == 128) return finish(H263MI_ERR_INVALID_INTRA_DC);      // IntraDc::from_u8, types.rs:930-936
+                        dc = (uint8_t)code;
+                        dc_taken = true;
+                        bpos += 8;
+                    }
+                    if (tcoef_left && (dc_taken || !intra) && bpos <= end64) {
+                        const BlockRun br = sorenson_v1 ? block_events_fast<true>(r.data(), bpos, end64, (uint32_t)zz, ev, t_tcoef)
+                                                        : block_events_fast<false>(r.data(), bpos, end64, (uint32_t)zz, ev, t_tcoef);
+                        if (br.rc != H263MI_OK) return finish(br.rc);
+                        bpos = br.pos; zz = br.zz; n_ev = br.n_ev; overrun = br.overrun; tcoef_left = br.more;
+                    }
+                    r.rollback(bpos);
+                }
+                if ((intra && !dc_taken) || tcoef_left)
+                rc = decode_block_to(r, sorenson, hdr.version, intra && !dc_taken, tcoef_left, dc, [&](bool, int run, int level) {
                     if (overrun) return;
                     zz += (size_t)run;
                     if (zz >= 64) { overrun = true; return; }

@@ -36,6 +36,7 @@ public:
     uint64_t peek_window() const { return window_at(pos_); }
     // the same at any bit position (hot loops keep their own cursor in a register and store it back with rollback())
     size_t size_bits() const { return nbits_; }
+    const uint8_t *data() const { return p_; }
     uint64_t window_at(size_t pos) const
     {
         const size_t byte = pos >> 3, nbytes = nbits_ >> 3;

@@ -110,7 +110,11 @@ int pt_compare_parser_paths(const uint8_t *data, size_t len, uint32_t options, i
     const int ra = parse_picture(data, len, options, nullptr, a), rb = parse_picture(data, len, options, nullptr, b);
     *rc_out = rb;
     if (ra != rb) return 1;
-    if (ra != H263MI_OK) return 0;                       // after an error the outputs mean nothing
+    if (ra != H263MI_OK) {                               // after an error the outputs mean nothing -- but the code must agree
+        ParsedPicture c;
+        c.want_dense = false;
+        return parse_picture(data, len, options, nullptr, c) == rb ? 0 : 11;
+    }
     if (a.bits_consumed != b.bits_consumed) return 2;
     if (memcmp(&a.desc, &b.desc, sizeof a.desc)) return 3;
     if (a.mbs.size() != b.mbs.size() || (a.mbs.size() && memcmp(a.mbs.data(), b.mbs.data(), a.mbs.size() * sizeof(h263mi_mb_record)))) return 4;
@@ -119,6 +123,16 @@ int pt_compare_parser_paths(const uint8_t *data, size_t len, uint32_t options, i
     if (a.block_first_event != b.block_first_event || a.n_coded_blocks != b.n_coded_blocks) return 7;
     if (a.next.have_last != b.next.have_last || a.next.last_format != b.next.last_format ||
         a.next.last_header_options != b.next.last_header_options) return 8;
+    // ... and the form the product runs: events only (want_dense = false), where the blocks go through the stand-alone event
+    // loops (block_events_short / _fast, inter_macroblock_events)
+    ParsedPicture c;
+    c.want_dense = false;
+    const int rcc = parse_picture(data, len, options, nullptr, c);
+    if (rcc != rb) return 11;
+    if (c.bits_consumed != b.bits_consumed) return 12;
+    if (c.mbs.size() != b.mbs.size() || (c.mbs.size() && memcmp(c.mbs.data(), b.mbs.data(), c.mbs.size() * sizeof(h263mi_mb_record)))) return 14;
+    if (c.events != b.events) return 16;
+    if (c.block_first_event != b.block_first_event || c.n_coded_blocks != b.n_coded_blocks) return 17;
     return 0;
 }
 

@@ -51,6 +51,20 @@ extern "C" int h263mi_debug_read_phases(unsigned long long *out, int reset)
 #endif
 // the same inside code that exists in two instantiations: the marker says which one
 #define ISA_MARK2(first, prefix_a, prefix_b, name) do { if (first) ISA_MARK(prefix_a name); else ISA_MARK(prefix_b name); } while (0)
+// COUNTING BUILDS ONLY (results wrong by construction; tools/phase_insts.sh): the waves of one kind stop behind a phase,
+// so that the launch's instruction counters (SQ_INSTS_VALU ...) of a series of such builds, differenced, say what every
+// phase EXECUTES -- the dynamic counterpart of tools/isa_mix.py's static table.  What a phase leaves behind is in LDS or
+// named in an empty asm, so that the compiler keeps everything in front of the stop.
+//   (9 = the waves of that kind return at once)
+//   H263MI_STOP_RECON  1 records + mark + compact   2 ... + every load issued and arrived   3 ... + row pass of round 0
+//                      4 ... + prediction into the strip   5 ... + all IDCT rounds (no store)
+//   H263MI_STOP_POST   1 strips fetched and in LDS   2 ... + horizontal edges   3 ... + vertical edges (no conversion, no store)
+#ifndef H263MI_STOP_RECON
+#define H263MI_STOP_RECON 0
+#endif
+#ifndef H263MI_STOP_POST
+#define H263MI_STOP_POST 0
+#endif
 
 // L2 prefetch through the SCALAR cache.  Every reconstruction wave starts with a load nothing can hide: its eight
 // records, read once, always an HBM miss (a timing experiment with the records of all pictures folded into 64 KB ran
@@ -227,6 +241,15 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     recon_phase_fetch<MC>(a, s, f, ln, p, km);      // every global load of this wave is in flight from here
     const uint32_t pf_tok = recon_prefetch_lines(ahead_coefs);      // ... and the L2 prefetch for a later wave behind them
     const int n_active = recon_n_active(km);
+#if H263MI_STOP_RECON == 2
+    {
+        for (int j = 0; j <= LUMA_ROWS; j++) asm volatile("" :: "v"(f.ly[j][0]), "v"(f.ly[j][1]), "v"(f.ly[j][2]));
+        for (int j = 0; j <= CHROMA_ROWS; j++) asm volatile("" :: "v"(f.ch[j][0]), "v"(f.ch[j][1]), "v"(f.ch[j][2]));
+        asm volatile("" :: "v"(f.coef0.x), "v"(f.coef0.y), "v"(f.coef0.z), "v"(f.coef0.w), "v"(f.flags), "v"(f.mvw[0]), "v"(f.mvw[1]));
+        recon_prefetch_lines_retire(pf_tok);
+        return;
+    }
+#endif
     ISA_MARK2(MC, "mc_", "intra_", "fetch_end");
     PHASE_MARK(2);
     // The first round is peeled off the loop: its coefficient row was requested by the fetch phase, ahead of the
@@ -236,6 +259,14 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     rs.ri.bad_events = 0;
     if (n_active > 0) recon_round_rows<true, MC>(a, s, f, ln, p, 0, km, rs);
     PHASE_MARK(3);
+#if H263MI_STOP_RECON == 3
+    {
+        for (int j = 0; j <= LUMA_ROWS; j++) asm volatile("" :: "v"(f.ly[j][0]), "v"(f.ly[j][1]), "v"(f.ly[j][2]));
+        for (int j = 0; j <= CHROMA_ROWS; j++) asm volatile("" :: "v"(f.ch[j][0]), "v"(f.ch[j][1]), "v"(f.ch[j][2]));
+        recon_prefetch_lines_retire(pf_tok);
+        return;
+    }
+#endif
     asm volatile("" : "+v"(ln));
     ISA_MARK2(MC, "mc_", "intra_", "predict_begin");
     recon_phase_predict<MC>(a, s, f, ln, p, km);    // waits for the reference rows
@@ -243,6 +274,9 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
     PHASE_MARK(4);
     wave_fence();                                   // the prediction is in the strip
     recon_prefetch_lines_retire(pf_tok);            // (the wave's own loads have arrived: so have these)
+#if H263MI_STOP_RECON == 4
+    return;
+#endif
     if (n_active > 0) recon_round_cols<MC>(s, ln, rs);
 #pragma unroll 1
     for (int round = 1; round * ROUND_BLOCKS < n_active; round++) {
@@ -250,6 +284,9 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
         recon_round_cols<MC>(s, ln, rs);
     }
     PHASE_MARK(5);
+#if H263MI_STOP_RECON == 5
+    return;
+#endif
     asm volatile("" : "+v"(ln));
     // event bounds that could not be used (only looked at when the caller said how many events there are): one report per wave
     if (a.events && a.n_events != 0xffffffffu) recon_report(a, ln, p.pic, false, __ballot(rs.ri.bad_events != 0) != 0);
@@ -263,6 +300,9 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
 __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan)
 {
     if (p.mby >= (int)a0.L.mbh) return;
+#if H263MI_STOP_RECON == 9
+    return;                                         // (counting build: the wave does nothing at all)
+#endif
     // A batch whose streams have drifted apart (dev_common.h: STREAM_*) says per stream where its reference lives, whether
     // it has one, and whether it takes part in this call at all (uniform: one scalar load per wave).
     ReconArgs a = a0;
@@ -302,6 +342,9 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     wave_fence();                                   // descriptors and chroma vectors are in LDS
     const CoefRange ahead_coefs = recon_prefetch_retire(a, pf);
     ISA_MARK("mark_end");
+#if H263MI_STOP_RECON == 1
+    return;
+#endif
     if (recon_wave_is_static(a, km, __ballot(ti.moving != 0) != 0)) {     // eight macroblocks that are not coded and do not move
         recon_phase_copy(a, ln, p);
         return;
@@ -400,14 +443,23 @@ __device__ __forceinline__ void post_strip(const PostArgs &a, PostStrip &s, Post
     if (FETCH_AHEAD) post_phase_fetch<INTERIOR>(a, pf, ln, sx, sy + 2, pic);
     ISA_MARK2(INTERIOR, "interior_", "edge_", "fetch_end");
     wave_fence();                                   // the strip is in LDS
+#if H263MI_STOP_POST == 1
+    return;
+#endif
     if (a.strength) {
         post_phase_hedges<INTERIOR>(a, s, ln, sx, sy);
         wave_fence();
         ISA_MARK2(INTERIOR, "interior_", "edge_", "hedges_end");
+#if H263MI_STOP_POST == 2
+        return;
+#endif
         post_phase_vedges<INTERIOR>(a, s, ln, sx, sy);
         wave_fence();
         ISA_MARK2(INTERIOR, "interior_", "edge_", "vedges_end");
     }
+#if H263MI_STOP_POST == 3
+    return;
+#endif
     post_phase_store<STREAM_RGBA, INTERIOR>(a, s, ln, sx, sy, pic);
     ISA_MARK2(INTERIOR, "interior_", "edge_", "store_end");
 }
@@ -447,6 +499,9 @@ template <bool STREAM_RGBA>
 __device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int lane, int sx, int ty, int pic)
 {
     if (ty >= (int)a0.tiles_y) return;
+#if H263MI_STOP_POST == 9
+    return;                                         // (counting build: the wave does nothing at all)
+#endif
     PostArgs a = a0;
     if (a0.stream_state) {                          // streams that have drifted apart (dev_common.h: STREAM_*): uniform
         const uint32_t st = a0.stream_state[pic];

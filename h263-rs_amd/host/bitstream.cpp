@@ -213,7 +213,7 @@ H263MI_TABLE(mvd_table, kMvdCodes)
 //   mvd_pair10[10 bits]            a horizontal and a vertical MVD code word (Table 14) that lie inside 10 bits together:
 //                                  len | (dx & 63) << 4 | (dy & 63) << 10 -- the small differences of slow motion
 namespace {
-constexpr uint32_t kEventLast = 1u << 4, kEventEscape = 1u << 5, kEventInvalid = 1u << 6;
+constexpr uint32_t kEventEscape = 1u << 5, kEventInvalid = 1u << 6;     // (bit 4: LAST)
 struct HeaderTables {
     uint16_t p12[4096], i12[4096], mvd10[1024];
     // tcoef13[13 bits]: EVERY TCOEF code word (12 bits at most, Table 16/H.263) together with its sign bit, as the event it
@@ -931,30 +931,27 @@ inline int16_t median3(int16_t a, int16_t b, int16_t c)
     return lo > m ? lo : m;
 }
 
-// predict_candidate (mvd_pred.rs:27-67); pv = vectors of the `current_mb` macroblocks decoded so far, 4 each
-// (`col`, `line`: position of the current macroblock, kept by the caller -- two 64-bit divisions per candidate
-// were a third of the time of a P picture)
-inline Mv predict_candidate(const Mv *pv, size_t current_mb, const Mv cur[4], size_t mb_per_line, int index, size_t col, size_t line)
+// predict_candidate (mvd_pred.rs:27-67).  The candidates are the macroblock to the left, the one above and the one above to
+// the right: only the current and the previous macroblock ROW are ever looked at, so the vectors of the macroblocks decoded so
+// far live in a ring of two rows (`row_cur`, `row_prev`: 4 vectors per macroblock; round 5 -- the array over the whole
+// picture was 130 KB written and read per 1080p picture beside the 261 KB of records).  `col`, `line`: position of the
+// current macroblock, kept by the caller.  (The reference's `last_line_mb < current_mb` tests hold whenever line > 0.)
+inline Mv predict_candidate(const Mv *row_cur, const Mv *row_prev, const Mv cur[4], size_t mb_per_line, int index, size_t col, size_t line)
 {
     const Mv zero{0, 0};
     Mv mv1;
-    if (index == 0 || index == 2) mv1 = col == 0 ? zero : pv[(current_mb - 1) * 4 + (size_t)index + 1];
+    if (index == 0 || index == 2) mv1 = col == 0 ? zero : row_cur[(col - 1) * 4 + (size_t)index + 1];
     else mv1 = cur[index - 1];
 
-    const size_t last_line_mb = (line ? line - 1 : 0) * mb_per_line + col;
     Mv mv2;
-    if (index <= 1) {
-        if (line == 0) mv2 = mv1;
-        else mv2 = last_line_mb < current_mb ? pv[last_line_mb * 4 + (size_t)index + 2] : mv1;
-    } else {
-        mv2 = cur[0];
-    }
+    if (index <= 1) mv2 = line == 0 ? mv1 : row_prev[col * 4 + (size_t)index + 2];
+    else mv2 = cur[0];
     const bool end_of_line = col == (mb_per_line ? mb_per_line - 1 : 0);
     Mv mv3;
     if (index <= 1) {
         if (end_of_line) mv3 = zero;
         else if (line == 0) mv3 = mv1;
-        else mv3 = last_line_mb + 1 < current_mb ? pv[(last_line_mb + 1) * 4 + 2] : mv1;
+        else mv3 = row_prev[(col + 1) * 4 + 2];
     } else {
         mv3 = cur[1];
     }
@@ -1066,8 +1063,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     // Output arrays at their largest size for this picture, written in place and cut to what was used at the end (no
     // per-element push_back; the event array grows by doubling, a macroblock at a time).
     static_assert(sizeof(Mv) == sizeof(uint32_t), "Mv is stored in ParsedPicture::scratch");
-    out.scratch.resize(total * 4);                   // vectors of the decoded macroblocks, 4 each
-    Mv *const pv = reinterpret_cast<Mv *>(out.scratch.data());
+    out.scratch.resize(2 * mb_per_line * 4);         // vectors of the current and the previous macroblock row, 4 per macroblock
+    Mv *const pv_rows = reinterpret_cast<Mv *>(out.scratch.data());
+    // the vectors of the macroblock at (mb_line, col)
+    const auto pv_at = [&](size_t line, size_t col) { return pv_rows + ((line & 1) * mb_per_line + col) * 4; };
     // the records go to the caller's array when it can hold the picture, else into out.mbs
     const bool ext = out.mbs_ext != nullptr && total <= out.mbs_ext_cap;
     out.mbs_ext_used = ext;
@@ -1138,18 +1137,19 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                         // four records whatever the run (what lies beyond it is written again by its own macroblock): short
                         // runs -- most of them -- then store without a loop whose trip count depends on the data
                         for (size_t k = 0; k < 4; k++) recs[n_mbs + k] = skipped;
-                        memset(pv + n_mbs * 4, 0, 4 * 4 * sizeof(Mv));
-                        if (run > 4) {
-                            for (size_t k = 4; k < run; k++) recs[n_mbs + k] = skipped;
-                            memset(pv + (n_mbs + 4) * 4, 0, (run - 4) * 4 * sizeof(Mv));
-                        }
+                        for (size_t k = 4; k < run; k++) recs[n_mbs + k] = skipped;
                     } else {
                         for (size_t k = 0; k < run; k++) recs[n_mbs + k] = skipped;
-                        memset(pv + n_mbs * 4, 0, run * 4 * sizeof(Mv));
                     }
                     n_mbs += run;
-                    mb_col += run;
-                    while (mb_col >= mb_per_line) { mb_col -= mb_per_line; mb_line++; }
+                    // zero vectors for the run, row segment by row segment of the two-row ring
+                    for (size_t left = run; left;) {
+                        const size_t seg = left < mb_per_line - mb_col ? left : mb_per_line - mb_col;
+                        memset(pv_at(mb_line, mb_col), 0, seg * 4 * sizeof(Mv));
+                        left -= seg;
+                        mb_col += seg;
+                        if (mb_col == mb_per_line) { mb_col = 0; mb_line++; }
+                    }
                     r.advance((uint32_t)run);
                     // The run ends in front of a coded macroblock (a zero bit) unless the window or the picture cut it short:
                     // that macroblock's header is taken out of the same window right away -- one trip through the loop, and one
@@ -1293,7 +1293,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             if (!intra) {                                                      // state.rs:229-285
                 const bool four = mb_type == H263MI_MB_INTER4V || mb_type == H263MI_MB_INTER4V_Q;
                 for (int k = 0; k < (four ? 4 : 1); k++) {
-                    const Mv pred = predict_candidate(pv, n_mbs, motion_vectors, mb_per_line, k, mb_col, mb_line);
+                    const Mv pred = predict_candidate(pv_at(mb_line, 0), pv_at(mb_line + 1, 0), motion_vectors, mb_per_line, k, mb_col, mb_line);
                     if (!umv) {
                         // halfpel_decode with the standard range: a sum outside [-32, 32) takes the other
                         // representative of the difference (mvd_pred.rs:70-117, HalfPel::invert types.rs:736-742)
@@ -1421,7 +1421,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         for (int k = 0; k < 4; k++) {
             rec.mv[k][0] = motion_vectors[k].x;
             rec.mv[k][1] = motion_vectors[k].y;
-            pv[n_mbs * 4 + (size_t)k] = motion_vectors[k];
+            pv_at(mb_line, mb_col)[k] = motion_vectors[k];
         }
         recs[n_mbs] = rec;
         n_mbs++;

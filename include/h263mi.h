@@ -475,11 +475,13 @@ int h263mi_mixed_stream_size(const h263mi_mixed *m, uint32_t stream, uint16_t *w
 /* number of size classes (fixed-geometry batches) alive.  A class no stream belongs to any more is given up when the next
  * class is made, so a stream that changes its size with every key frame does not make the set grow. */
 uint32_t h263mi_mixed_size_classes(const h263mi_mixed *m);
-/* Device memory of the set's frame stores.  A class holds two frames of its size for EVERY stream of the set (slot = stream
- * index), whatever the number of its members, and picture sizes come out of untrusted bitstreams: a picture whose new class
- * would take the frame stores of the set beyond the limit is refused for its stream with H263MI_ERR_OUT_OF_MEMORY (the stream
- * keeps its state; classes nobody belongs to are given up first).  The default limit is half of the device's memory;
- * 0 = no limit. */
+/* Device memory of the set's frame stores.  A class holds two frames of its size per SLOT, and it has as many slots as it has
+ * members, rounded up to a power of two (doubled when a stream joins a full class -- the members' frames move into the new
+ * store --, halved when three quarters stand empty): 63 QCIF streams and one 1080p stream hold 64 x 2 QCIF frames and
+ * 1 x 2 1080p frames.  Picture sizes come out of untrusted bitstreams: a picture whose class would take the frame stores of
+ * the set beyond the limit (while a class grows, its old and its new store count both) is refused for its stream with
+ * H263MI_ERR_OUT_OF_MEMORY (the stream keeps its state; classes nobody belongs to are given up first).  The default limit is
+ * half of the device's memory; 0 = no limit. */
 int h263mi_mixed_set_memory_limit(h263mi_mixed *m, uint64_t bytes);
 uint64_t h263mi_mixed_frame_store_bytes(const h263mi_mixed *m);
 /* DecodedPicture::as_yuv of stream `stream`'s last picture: tightly packed planes to HOST memory */

@@ -512,9 +512,13 @@ def simlib_pad(mbs, w, h):
 # 4 094 non-zero 12-bit LEVELs at every quantiser 1..31 -- all overflow and saturation cases included -- as the AC
 # coefficients of Full-class intra blocks, and as inter blocks over a flat prediction, against the oracle.
 # ---------------------------------------------------------------------------------------------
-def test_every_level_at_every_quantiser_dequantises_like_the_oracle():
+@pytest.mark.parametrize("span", [511, 2047], ids=["within_9_bits", "12_bits"])
+def test_every_level_at_every_quantiser_dequantises_like_the_oracle(span):
+    """span = 511: no LEVEL outside [-512, 511] anywhere, so every IDCT round takes the saturating 16 x form (round 5: a round
+    that holds a wider LEVEL takes the wrapping form instead, tests/test_gpu_round5.py) -- its saturation at 12 bits is what
+    the dequant mutant breaks; span = 2047: every 12-bit LEVEL, the reference's i16 wrap included (the oracle wraps too)."""
     w, h = 176, 144                                            # 99 macroblocks = 594 blocks of 63 AC coefficients
-    levels = np.array([v for v in range(-2047, 2048) if v != 0], np.int16)
+    levels = np.array([v for v in range(-span, span + 1) if v != 0], np.int16)
     n_blocks = 99 * 6
     rng = np.random.default_rng(7)
     for q in range(1, 32):

@@ -239,3 +239,112 @@ def test_mixed_set_survives_a_failure_at_any_hip_call(pipeline):
             pytest.fail("sweep %d never went through" % sweep)
     assert failures >= 8 and through == 3, (failures, through)
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# h263mi_mixed: slots by membership.  A class owns as many slots as it has members (a power of two):
+# 63 QCIF streams and one 1080p stream hold 64 x 2 QCIF frames and 1 x 2 1080p frames -- round 4 held 64 x 2 of both --;
+# a class grows by doubling when streams join it (the members' frames move into the new store: the P pictures that follow
+# must predict from them) and gives room back when three quarters of it stand empty.
+# ---------------------------------------------------------------------------------------------
+def _frame_bytes(w, h):
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    pitch_c = (mbw * 8 + 63) // 64 * 64
+    raw = 2 * pitch_c * mbh * 16 + 2 * pitch_c * mbh * 8 + 256
+    return (raw + 255) // 256 * 256
+
+
+class _MixedChains:
+    """n streams through a MixedBatch, every one against its own oracle chain"""
+
+    def __init__(self, n, pipeline):
+        import recgen
+        import sorenson_enc as enc
+        from test_bitstream_e2e import make_codable
+        self.recgen, self.enc, self.make_codable = recgen, enc, make_codable
+        self.n, self.q = n, 6
+        self.m = h263mi.MixedBatch(n, pipeline_post=pipeline)
+        self.refs, self.size, self.count = [None] * n, [None] * n, 0
+
+    def picture(self, s, intra, size):
+        w, h = size
+        self.count += 1
+        if intra:
+            mbs, co = self.recgen.intra_picture(w, h, seed=31 * self.count + s, max_level=60)
+            mbs = self.make_codable(mbs, self.q, s, 0)
+        else:
+            mbs, co = self.recgen.inter_picture(w, h, seed=31 * self.count + s, mv_range=24, p_4v=0.2, p_coded=0.4, quant=self.q, max_level=60)
+            mbs = self.make_codable(mbs, self.q, s + self.count, 1)
+        rc, self.refs[s] = orc.decode_picture(w, h, mbs, co, None if intra else self.refs[s])
+        assert rc == 0
+        self.size[s] = size
+        return self.enc.encode_picture(w, h, 0 if intra else 1, self.q, mbs, co, temporal_reference=self.count % 256)
+
+    def call(self, plan):
+        """plan: {stream: ('I' | 'P', size)}; streams not named sit the call out"""
+        datas = [None] * self.n
+        for s, (kind, size) in plan.items():
+            datas[s] = self.picture(s, kind == "I", size)
+        used, rcs, descs = self.m.decode_next_pictures(datas, n_threads=3)
+        assert not any(rcs), rcs
+        assert not any(self.m.sync())
+
+    def check(self, what):
+        for s in range(self.n):
+            if self.refs[s] is not None:
+                assert self.m.stream_size(s) == self.size[s]
+                assert_planes_equal(self.m.copy_yuv(s), self.refs[s], "%s, stream %d" % (what, s))
+
+
+def test_mixed_frame_store_follows_the_membership():
+    n = 64
+    ch = _MixedChains(n, pipeline=True)
+    qcif, hd = (176, 144), (1920, 1080)
+    ch.call({s: ("I", hd if s == 17 else qcif) for s in range(n)})
+    want = 2 * (64 * _frame_bytes(*qcif) + 1 * _frame_bytes(*hd))        # 63 members in 64 slots, 1 member in 1 slot
+    assert ch.m.frame_store_bytes() == want, (ch.m.frame_store_bytes(), want)
+    assert want < 2 * n * _frame_bytes(*hd) // 20                        # (round 4: 64 x 2 frames of BOTH sizes, 410 MB)
+    ch.call({s: ("P", ch.size[s]) for s in range(n)})
+    ch.check("one P picture each")
+    ch.m.close()
+
+
+@pytest.mark.parametrize("pipeline", [False, True], ids=["plain", "pipelined"])
+def test_mixed_class_grows_by_doubling_and_shrinks_and_keeps_its_pictures(pipeline):
+    n = 20
+    ch = _MixedChains(n, pipeline)
+    cif, qcif = (352, 288), (176, 144)
+    fb = _frame_bytes(*cif)
+    ch.call({0: ("I", cif)})
+    assert ch.m.frame_store_bytes() == 2 * 1 * fb
+    # streams join one or two at a time: 1 -> 2 -> 4 -> 8 -> 16 slots, every member predicting across every move
+    joined = 1
+    for step, add in enumerate((1, 1, 2, 3, 1, 4, 3)):                   # 2, 3, 5, 8, 9, 13, 16 members
+        plan = {s: ("P", cif) for s in range(joined)}
+        for s in range(joined, joined + add):
+            plan[s] = ("I", cif)
+        joined += add
+        ch.call(plan)
+        slots = 1
+        while slots < joined:
+            slots *= 2
+        assert ch.m.frame_store_bytes() == 2 * slots * fb, (step, joined, ch.m.frame_store_bytes() // (2 * fb))
+        ch.check("after %d streams have joined" % joined)
+    assert joined == 16 and ch.m.size_classes() == 1
+    # twelve of the sixteen move to QCIF (an I picture each): the CIF class stands three quarters empty and gives the room back
+    plan = {s: ("I", qcif) for s in range(4, 16)}
+    plan.update({s: ("P", cif) for s in range(4)})
+    ch.call(plan)
+    ch.check("twelve streams have left")
+    ch.call({s: ("P", ch.size[s]) for s in range(16)})                   # (the class is rebuilt in front of its next launch)
+    ch.check("after the shrink")
+    assert ch.m.size_classes() == 2
+    assert ch.m.frame_store_bytes() == 2 * (4 * fb + 16 * _frame_bytes(*qcif)), ch.m.frame_store_bytes()
+    # a stream that is reset gives its slot up; the next joiner takes it
+    ch.m.reset_stream(2)
+    ch.refs[2] = None
+    ch.call({18: ("I", cif), 0: ("P", cif)})
+    assert ch.m.frame_store_bytes() == 2 * (4 * fb + 16 * _frame_bytes(*qcif))
+    ch.call({s: ("P", ch.size[s]) for s in (0, 1, 3, 18)})
+    ch.check("a freed slot taken again")
+    ch.m.close()

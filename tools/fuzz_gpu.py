@@ -207,7 +207,7 @@ def run(budget=60.0, seed=1, verbose=True):
                             rng.integers(260, 800), 4 * rng.integers(65, 200)]))
         h = int(rng.choice([rng.integers(1, 64), rng.integers(1, 300), 16 * rng.integers(1, 20), 144, 288,
                             rng.integers(64, 420), 4 * rng.integers(16, 100)]))
-        if rng.random() < 0.08:
+        if rng.random() < (1.0 if os.environ.get("H263MI_FUZZ_MIXED_ONLY") else 0.08):      # (the switch: a run of mixed sets only)
             n_pic, n_px = fuzz_mixed(rng, seed, n_pic, n_px)
             continue
         if rng.random() < 0.2:

@@ -4,6 +4,13 @@
 
 #include <cstdlib>
 #include <cstring>
+// H263MI_NT_RECORDS (experiment, off): records written with non-temporal stores (see store_record in parse_picture)
+#if defined(H263MI_NT_RECORDS) && defined(__SSE2__)
+#include <emmintrin.h>
+#define H263MI_STREAM_RECORDS 1
+#else
+#define H263MI_STREAM_RECORDS 0
+#endif
 
 namespace h263mi {
 namespace bits {
@@ -1078,7 +1085,27 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     uint32_t *const first_event = out.block_first_event.data();
     first_event[0] = 0;
     size_t n_mbs = 0, n_events = 0, n_blocks = 0;
+    // H263MI_NT_RECORDS (experiment): a record is written once and never read again by this thread -- in the product it lies
+    // in pinned staging memory that only the copy engine reads: non-temporal stores (no read-for-ownership of the line, no
+    // place taken in the caches the parser's tables and the bitstream live in; 261 KB of records per 1080p picture), with a
+    // fence in front of the return.  Measured: see profiles/README.md (round 5).
+    const auto store_record = [](h263mi_mb_record *dst, const h263mi_mb_record &src) {
+#if H263MI_STREAM_RECORDS
+        if (((uintptr_t)dst & 15u) == 0) {
+            __m128i lo, hi;
+            __builtin_memcpy(&lo, &src, 16);
+            __builtin_memcpy(&hi, reinterpret_cast<const uint8_t *>(&src) + 16, 16);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst), lo);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst) + 1, hi);
+            return;
+        }
+#endif
+        *dst = src;
+    };
     const auto finish = [&](int code) {
+#if H263MI_STREAM_RECORDS
+        _mm_sfence();
+#endif
         if (ext) out.n_mbs_ext = n_mbs < total ? n_mbs : total;
         else out.mbs.resize(n_mbs);
         out.block_first_event.resize(n_blocks + 1);
@@ -1133,14 +1160,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                     h263mi_mb_record skipped{};
                     skipped.mb_type = H263MI_MB_INTER;
                     skipped.quant = (uint8_t)(in_force_quantizer < 1 ? 1 : in_force_quantizer);
-                    if (n_mbs + 4 <= total) {
-                        // four records whatever the run (what lies beyond it is written again by its own macroblock): short
-                        // runs -- most of them -- then store without a loop whose trip count depends on the data
-                        for (size_t k = 0; k < 4; k++) recs[n_mbs + k] = skipped;
-                        for (size_t k = 4; k < run; k++) recs[n_mbs + k] = skipped;
-                    } else {
-                        for (size_t k = 0; k < run; k++) recs[n_mbs + k] = skipped;
-                    }
+                    for (size_t k = 0; k < run; k++) store_record(recs + n_mbs + k, skipped);
                     n_mbs += run;
                     // zero vectors for the run, row segment by row segment of the two-row ring
                     for (size_t left = run; left;) {
@@ -1423,7 +1443,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             rec.mv[k][1] = motion_vectors[k].y;
             pv_at(mb_line, mb_col)[k] = motion_vectors[k];
         }
-        recs[n_mbs] = rec;
+        store_record(recs + n_mbs, rec);
         n_mbs++;
         if (++mb_col == mb_per_line) { mb_col = 0; mb_line++; }
     }

@@ -311,8 +311,16 @@ struct h263mi_batch {
         uint32_t *h_events = nullptr, *d_events = nullptr;   // sparse transport: rebased block offsets, then events
         size_t cap_blocks = 0, cap_events = 0;
         hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
+        hipEvent_t copied = nullptr;           // recorded on the copy stream behind the slot's host-to-device copies
     } host_stg[2];
     unsigned host_slot = 0;
+    // The host-to-device copies of a call go on a stream of their own (round 5): 16.7 MB of records per call of 64 x 1080p take
+    // the link 0.3 ms, the kernel 0.2-0.25 ms, and queued on ONE stream they ran one after the other -- 0.55 ms of stream time
+    // per call, which is what a call took once the host parser had become faster than that.  With the copies beside the
+    // previous call's kernel (the two staging slots make that legal) the stream is busy for the longer of the two.
+    // H263MI_COPY_STREAM=0: everything on the batch's stream again.
+    hipStream_t copy_stream = nullptr;
+    bool copy_stream_tried = false;
     // h263mi_batch_decode_next_pictures: what each stream remembers of its last picture header (state.rs:143-167)
     // and the parse results of the current call (kept between calls so that their buffers are reused)
     std::vector<bits::ParserContext> parser_ctx;
@@ -510,6 +518,11 @@ struct h263mi_batch {
             if (g2.h_events) (void)hipHostFree(g2.h_events);
             if (g2.d_events) (void)hipFree(g2.d_events);
             if (g2.done) (void)hipEventDestroy(g2.done);
+            if (g2.copied) (void)hipEventDestroy(g2.copied);
+        }
+        if (copy_stream) {
+            (void)hipStreamSynchronize(copy_stream);
+            (void)hipStreamDestroy(copy_stream);
         }
     }
 
@@ -524,6 +537,14 @@ struct h263mi_batch {
         if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
         if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
         if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
+        if (!g2.copied) HIP_TRY(hipEventCreateWithFlags(&g2.copied, hipEventDisableTiming));
+        if (!copy_stream_tried) {
+            copy_stream_tried = true;
+            const char *env = getenv("H263MI_COPY_STREAM");
+            if (!(env && env[0] == '0') && !fault_now() &&
+                hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess)
+                copy_stream = nullptr;           // (without it the copies go on the batch's stream, as before)
+        }
         return H263MI_OK;
     }
 
@@ -1176,30 +1197,56 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
     const auto t_enq0 = std::chrono::steady_clock::now();
     RC_TRY(b->time_close());                     // the copies below are not part of any kernel's time
-    // the records of the streams that take part, one copy per run of neighbouring streams (all of them: one copy)
-    for (uint32_t i = 0; i < b->n;) {
-        if (!b->ss[i].active) { i++; continue; }
-        uint32_t j = i + 1;
-        while (j < b->n && b->ss[j].active) j++;
-        HIP_TRY(hipMemcpyAsync(g2.d_mbs + (size_t)i * per, g2.h_mbs + (size_t)i * per, (size_t)(j - i) * per * sizeof(MbRecord),
-                               hipMemcpyHostToDevice, b->stream));
-        i = j;
+    // (on the copy stream when there is one: beside the kernel of the call before, which reads the OTHER staging slot; the
+    // device buffers of this slot were last read by the kernel of two calls ago, whose `done` event the host has waited for)
+    hipStream_t cs = b->copy_stream ? b->copy_stream : b->stream;
+    const auto enqueue_copies = [&]() -> int {
+        // the records of the streams that take part, one copy per run of neighbouring streams (all of them: one copy)
+        for (uint32_t i = 0; i < b->n;) {
+            if (!b->ss[i].active) { i++; continue; }
+            uint32_t j = i + 1;
+            while (j < b->n && b->ss[j].active) j++;
+            HIP_TRY(hipMemcpyAsync(g2.d_mbs + (size_t)i * per, g2.h_mbs + (size_t)i * per, (size_t)(j - i) * per * sizeof(MbRecord),
+                                   hipMemcpyHostToDevice, cs));
+            i = j;
+        }
+        HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+        if (sparse && blocks) {
+            h_first[blocks] = (uint32_t)n_ev;
+            HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        } else if (blocks) {
+            HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, cs));
+        }
+        if (cs != b->stream) {                   // the kernel waits for the copies
+            HIP_TRY(hipEventRecord(g2.copied, cs));
+            HIP_TRY(hipStreamWaitEvent(b->stream, g2.copied, 0));
+        }
+        return H263MI_OK;
+    };
+    {
+        const int crc = enqueue_copies();
+        if (crc != H263MI_OK) {
+            // nothing is launched: no copy may still be reading this slot's host memory when a later call fills it again
+            (void)hipStreamSynchronize(cs);
+            return crc;
+        }
     }
-    HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     if (sparse && blocks) {
-        h_first[blocks] = (uint32_t)n_ev;
-        HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
         // the reconstruction waves read the events themselves (recon_kernel.inl: coeff_row_from_events); round 2 had a
         // kernel of its own (k_expand) rebuild dense blocks in HBM first
         b->cur_first_event = g2.d_events;
         b->cur_events = g2.d_events + blocks + 1;
         b->cur_n_events = (uint32_t)n_ev;
-    } else if (blocks) {
-        HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, b->stream));
     }
     b->coeff_pool_blocks = blocks;
     b->coeff_checked = true;
-    RC_TRY(b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types));
+    {
+        const int src = b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types);
+        if (src != H263MI_OK) {
+            if (cs != b->stream) (void)hipStreamSynchronize(cs);       // (no copy left behind that reads this slot)
+            return src;
+        }
+    }
     // ---- the launch is queued and the streams have advanced: nothing below may turn that into an error
     // (timing: the bracket ends right behind the launch -- closed at the next call it would hold the time the device
     // idles while the host parses the next pictures)
@@ -1287,7 +1334,12 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
     h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];
     RC_TRY(b->ensure_record_staging(g2));
-    HIP_TRY(hipEventSynchronize(g2.done));
+    {
+        // (this is where a call waits when the GPU stream -- copies + kernel of two calls ago -- is the slower side)
+        const auto t_wait = std::chrono::steady_clock::now();
+        HIP_TRY(hipEventSynchronize(g2.done));
+        if (b->trace_host) b->host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
+    }
     const size_t per = (size_t)b->L.mbw * b->L.mbh;
     // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
     std::vector<int> rcs(n, H263MI_OK);

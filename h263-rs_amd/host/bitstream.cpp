@@ -4,8 +4,9 @@
 
 #include <cstdlib>
 #include <cstring>
-// H263MI_NT_RECORDS (experiment, off): records written with non-temporal stores (see store_record in parse_picture)
-#if defined(H263MI_NT_RECORDS) && defined(__SSE2__)
+// Records are written with non-temporal stores where the target has them (see store_record in parse_picture);
+// -DH263MI_NO_NT_RECORDS: plain stores
+#if !defined(H263MI_NO_NT_RECORDS) && defined(__SSE2__)
 #include <emmintrin.h>
 #define H263MI_STREAM_RECORDS 1
 #else
@@ -1085,10 +1086,11 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     uint32_t *const first_event = out.block_first_event.data();
     first_event[0] = 0;
     size_t n_mbs = 0, n_events = 0, n_blocks = 0;
-    // H263MI_NT_RECORDS (experiment): a record is written once and never read again by this thread -- in the product it lies
-    // in pinned staging memory that only the copy engine reads: non-temporal stores (no read-for-ownership of the line, no
-    // place taken in the caches the parser's tables and the bitstream live in; 261 KB of records per 1080p picture), with a
-    // fence in front of the return.  Measured: see profiles/README.md (round 5).
+    // A record is written once and never read again by this thread -- in the product it lies in pinned staging memory that
+    // only the copy engine reads: non-temporal stores (no read-for-ownership of the line, no place taken in the caches the
+    // parser's tables and the bitstream live in; 261 KB of records per 1080p picture), with a fence in front of the return.
+    // On the GPU boxes' EPYC: realistic P pictures 10.2 k -> 12.2 k pictures/s on one thread, 137 k -> 171 k on 16 (records
+    // into a 16.7 MB ring, the shape of the batch staging); key frames +-0 (profiles/r05_f_nt_records.txt).
     const auto store_record = [](h263mi_mb_record *dst, const h263mi_mb_record &src) {
 #if H263MI_STREAM_RECORDS
         if (((uintptr_t)dst & 15u) == 0) {

@@ -311,16 +311,8 @@ struct h263mi_batch {
         uint32_t *h_events = nullptr, *d_events = nullptr;   // sparse transport: rebased block offsets, then events
         size_t cap_blocks = 0, cap_events = 0;
         hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
-        hipEvent_t copied = nullptr;           // recorded on the copy stream behind the slot's host-to-device copies
     } host_stg[2];
     unsigned host_slot = 0;
-    // The host-to-device copies of a call go on a stream of their own (round 5): 16.7 MB of records per call of 64 x 1080p take
-    // the link 0.3 ms, the kernel 0.2-0.25 ms, and queued on ONE stream they ran one after the other -- 0.55 ms of stream time
-    // per call, which is what a call took once the host parser had become faster than that.  With the copies beside the
-    // previous call's kernel (the two staging slots make that legal) the stream is busy for the longer of the two.
-    // H263MI_COPY_STREAM=0: everything on the batch's stream again.
-    hipStream_t copy_stream = nullptr;
-    bool copy_stream_tried = false;
     // h263mi_batch_decode_next_pictures: what each stream remembers of its last picture header (state.rs:143-167)
     // and the parse results of the current call (kept between calls so that their buffers are reused)
     std::vector<bits::ParserContext> parser_ctx;
@@ -518,11 +510,6 @@ struct h263mi_batch {
             if (g2.h_events) (void)hipHostFree(g2.h_events);
             if (g2.d_events) (void)hipFree(g2.d_events);
             if (g2.done) (void)hipEventDestroy(g2.done);
-            if (g2.copied) (void)hipEventDestroy(g2.copied);
-        }
-        if (copy_stream) {
-            (void)hipStreamSynchronize(copy_stream);
-            (void)hipStreamDestroy(copy_stream);
         }
     }
 
@@ -537,14 +524,6 @@ struct h263mi_batch {
         if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
         if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
         if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
-        if (!g2.copied) HIP_TRY(hipEventCreateWithFlags(&g2.copied, hipEventDisableTiming));
-        if (!copy_stream_tried) {
-            copy_stream_tried = true;
-            const char *env = getenv("H263MI_COPY_STREAM");
-            if (!(env && env[0] == '0') && !fault_now() &&
-                hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess)
-                copy_stream = nullptr;           // (without it the copies go on the batch's stream, as before)
-        }
         return H263MI_OK;
     }
 
@@ -1197,9 +1176,11 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
     const auto t_enq0 = std::chrono::steady_clock::now();
     RC_TRY(b->time_close());                     // the copies below are not part of any kernel's time
-    // (on the copy stream when there is one: beside the kernel of the call before, which reads the OTHER staging slot; the
-    // device buffers of this slot were last read by the kernel of two calls ago, whose `done` event the host has waited for)
-    hipStream_t cs = b->copy_stream ? b->copy_stream : b->stream;
+    // (A stream of their own for these copies -- beside the kernel of the call before -- was measured in round 5 and dropped:
+    // the wait for the staging slot went from 0.15 ms to 0.01 ms per call, and the call as a whole from 0.60 to 0.68 ms: the
+    // copies are blit kernels, they then share the CUs with k_frame and the host's memory with the parser threads.
+    // profiles/r05_g_e2e_per_call*.txt)
+    hipStream_t cs = b->stream;
     const auto enqueue_copies = [&]() -> int {
         // the records of the streams that take part, one copy per run of neighbouring streams (all of them: one copy)
         for (uint32_t i = 0; i < b->n;) {
@@ -1216,10 +1197,6 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         } else if (blocks) {
             HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, cs));
-        }
-        if (cs != b->stream) {                   // the kernel waits for the copies
-            HIP_TRY(hipEventRecord(g2.copied, cs));
-            HIP_TRY(hipStreamWaitEvent(b->stream, g2.copied, 0));
         }
         return H263MI_OK;
     };
@@ -1243,7 +1220,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     {
         const int src = b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types);
         if (src != H263MI_OK) {
-            if (cs != b->stream) (void)hipStreamSynchronize(cs);       // (no copy left behind that reads this slot)
+            (void)hipStreamSynchronize(cs);      // (no copy left behind that reads this slot)
             return src;
         }
     }

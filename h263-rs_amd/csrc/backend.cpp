@@ -295,6 +295,8 @@ struct h263mi_batch {
     hipEvent_t state_copied[kStateSlots] = {nullptr, nullptr, nullptr, nullptr};
     unsigned state_slot = 0;
     const uint32_t *cur_first_event = nullptr, *cur_events = nullptr;   // sparse transport of the next submit (then cleared)
+    const uint32_t *cur_group_index = nullptr;   // sparse RECORDS of the next submit (ReconArgs::mb_group_index; then cleared)
+    const uint64_t *cur_mb_base = nullptr;
     uint32_t cur_n_events = 0;                 // ... and how many event words there are (0 = the caller did not say)
     uint64_t coeff_pool_blocks = 0;            // size of the pool the next submit reads ...
     bool coeff_checked = false;                // ... when the caller told us (host entry points do; device pointers do not)
@@ -307,7 +309,8 @@ struct h263mi_batch {
     struct HostStaging {
         MbRecord *h_mbs = nullptr, *d_mbs = nullptr;
         int16_t *h_coeffs = nullptr, *d_coeffs = nullptr;
-        uint64_t *h_base = nullptr, *d_base = nullptr;
+        uint64_t *h_base = nullptr, *d_base = nullptr;       // [0, n): coefficient base per stream; [n, 2n): record base (sparse records)
+        uint32_t *h_index = nullptr, *d_index = nullptr;     // sparse records: one word per group of 8 macroblocks, stream after stream
         uint32_t *h_events = nullptr, *d_events = nullptr;   // sparse transport: rebased block offsets, then events
         size_t cap_blocks = 0, cap_events = 0;
         hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
@@ -507,6 +510,8 @@ struct h263mi_batch {
             if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
             if (g2.h_base) (void)hipHostFree(g2.h_base);
             if (g2.d_base) (void)hipFree(g2.d_base);
+            if (g2.h_index) (void)hipHostFree(g2.h_index);
+            if (g2.d_index) (void)hipFree(g2.d_index);
             if (g2.h_events) (void)hipHostFree(g2.h_events);
             if (g2.d_events) (void)hipFree(g2.d_events);
             if (g2.done) (void)hipEventDestroy(g2.done);
@@ -521,8 +526,11 @@ struct h263mi_batch {
         // each piece on its own, so that a failed allocation leaves nothing half-initialised for the next call
         if (!g2.h_mbs) HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
         if (!g2.d_mbs) HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
-        if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
-        if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, (size_t)n * sizeof(uint64_t)));
+        if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, 2 * (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
+        if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, 2 * (size_t)n * sizeof(uint64_t)));
+        const size_t index_words = (size_t)n * recon_tiles_x(L) * L.mbh;
+        if (!g2.h_index) HIP_TRY(hipHostMalloc((void **)&g2.h_index, index_words * sizeof(uint32_t), hipHostMallocDefault));
+        if (!g2.d_index) HIP_TRY(hipMalloc((void **)&g2.d_index, index_words * sizeof(uint32_t)));
         if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
         return H263MI_OK;
     }
@@ -616,6 +624,11 @@ struct h263mi_batch {
         a.n_events = cur_n_events ? cur_n_events : 0xffffffffu;
         cur_first_event = cur_events = nullptr;
         cur_n_events = 0;
+        a.mb_group_index = cur_group_index;
+        a.mb_base = cur_mb_base;
+        a.groups_per_picture = recon_tiles_x(L) * L.mbh;
+        cur_group_index = nullptr;
+        cur_mb_base = nullptr;
         a.coeff_base = d_coeff_base;
         a.status = d_status;
         a.coeff_pool_blocks = coeff_pool_blocks;
@@ -1077,8 +1090,13 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                              const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks,
                              const uint32_t *const *first_event, const uint32_t *const *events, const uint32_t *n_events,
                              bool from_parser = false, uint32_t pack_threads = 0, const uint8_t *types = nullptr,
-                             bool deferred_post = false)
+                             bool deferred_post = false, const uint32_t *const *group_index = nullptr)
 {
+    // group_index (from the parser only): SPARSE RECORDS -- mbs[i] holds the n_mbs[i] records of stream i's coded macroblocks
+    // (written in place at the head of the stream's part of the staging slot) and group_index[i] one word per group of 8
+    // macroblocks (bits::ParsedPicture::sparse_records, ReconArgs::mb_group_index): what crosses the link is the head of every
+    // stream's part, as long as the longest of them -- one 2-D copy; a third of the bytes of the dense arrays on real content
+    const bool sparse_rec = group_index != nullptr && from_parser;
     // from_parser: the arrays are what bits::parse_picture just wrote (h263mi_batch_decode_next_pictures) -- valid by
     // construction, so the per-record checks a caller's arrays get are skipped; pack_threads: the caller's thread budget
     const bool sparse = first_event != nullptr;
@@ -1115,12 +1133,16 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     pad.mb_type = H263MI_MB_INTER;
     pad.quant = 1;
     std::vector<uint32_t> ev_base(b->n + 1, 0);
-    size_t at = 0;
+    size_t at = 0, rec_at = 0;
+    const size_t groups_pp = (size_t)recon_tiles_x(b->L) * b->L.mbh;
     for (uint32_t i = 0; i < b->n; i++) {        // coeff_index of stream i counts from its own first block
         g2.h_base[i] = at;
         at += n_coeff_blocks[i];
         ev_base[i + 1] = ev_base[i] + (sparse ? n_events[i] : 0);
+        g2.h_base[b->n + i] = (uint64_t)i * per; // (sparse records: stream i's first record)
+        if (sparse_rec && b->ss[i].active && n_mbs[i] > rec_at) rec_at = n_mbs[i];
     }
+    const size_t records_sent = sparse_rec ? rec_at : 0;         // records of the stream that has the most
     uint32_t *h_first = g2.h_events, *h_ev = sparse ? g2.h_events + blocks + 1 : nullptr;
     std::atomic<bool> offsets_ok{true}, records_ok{true};
     // packing is a host memcpy of every record byte: a few threads, or one core caps the rate below the PCIe link
@@ -1128,6 +1150,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         for (uint32_t i = first; i < last; i += step) {
             if (!b->ss[i].active) continue;      // sits the call out: its records are never read (STREAM_RECON_SKIP)
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
+            if (sparse_rec) memcpy(g2.h_index + (size_t)i * groups_pp, group_index[i], groups_pp * sizeof(uint32_t));
             for (uint32_t k = 0; k < n_mbs[i] && !from_parser; k++) {   // the same checks as h263mi_submit_picture
                 const MbRecord &m = mbs[i][k];
                 // (a record without coded blocks does not use its coeff_index)
@@ -1137,7 +1160,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             }
             // (h263mi_batch_decode_next_pictures has its parser write the records straight into this slot)
             if (n_mbs[i] && mbs[i] != dst) memcpy(dst, mbs[i], (size_t)n_mbs[i] * sizeof(MbRecord));
-            for (size_t k = n_mbs[i]; k < per; k++) dst[k] = pad;
+            for (size_t k = n_mbs[i]; k < per && !sparse_rec; k++) dst[k] = pad;      // (sparse records: no record = not coded)
             if (!n_coeff_blocks[i]) continue;
             if (!sparse) {
                 memcpy(g2.h_coeffs + g2.h_base[i] * 64, coeffs[i], (size_t)n_coeff_blocks[i] * 128);
@@ -1164,7 +1187,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
             }
         }
     };
-    const size_t bytes = (size_t)b->n * per * sizeof(MbRecord) + (sparse ? event_words * 4 : blocks * 128);
+    const size_t bytes = (sparse_rec ? records_sent * b->n : (size_t)b->n * per) * sizeof(MbRecord) + (sparse ? event_words * 4 : blocks * 128);
     const uint32_t n_thr = bytes < (4u << 20) ? 1u
                          : std::min<uint32_t>({pack_threads ? pack_threads : 8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
     if (n_thr <= 1) {
@@ -1182,8 +1205,15 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     // profiles/r05_g_e2e_per_call*.txt)
     hipStream_t cs = b->stream;
     const auto enqueue_copies = [&]() -> int {
+        if (sparse_rec) {
+            // sparse records: the head of every stream's part in one 2-D copy, the index words in another
+            if (records_sent)
+                HIP_TRY(hipMemcpy2DAsync(g2.d_mbs, per * sizeof(MbRecord), g2.h_mbs, per * sizeof(MbRecord), records_sent * sizeof(MbRecord),
+                                         b->n, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(g2.d_index, g2.h_index, (size_t)b->n * groups_pp * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        }
         // the records of the streams that take part, one copy per run of neighbouring streams (all of them: one copy)
-        for (uint32_t i = 0; i < b->n;) {
+        for (uint32_t i = 0; i < b->n && !sparse_rec;) {
             if (!b->ss[i].active) { i++; continue; }
             uint32_t j = i + 1;
             while (j < b->n && b->ss[j].active) j++;
@@ -1191,7 +1221,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                                    hipMemcpyHostToDevice, cs));
             i = j;
         }
-        HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, 2 * (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
         if (sparse && blocks) {
             h_first[blocks] = (uint32_t)n_ev;
             HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
@@ -1217,6 +1247,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     }
     b->coeff_pool_blocks = blocks;
     b->coeff_checked = true;
+    if (sparse_rec) {
+        b->cur_group_index = g2.d_index;
+        b->cur_mb_base = g2.d_base + b->n;
+    }
     {
         const int src = b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types);
         if (src != H263MI_OK) {
@@ -1318,6 +1352,8 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         if (b->trace_host) b->host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
     }
     const size_t per = (size_t)b->L.mbw * b->L.mbh;
+    // H263MI_SPARSE_RECORDS=0: dense record arrays over the link, as rounds 2-4 sent them (A/B switch)
+    static const bool sparse_rec = !(getenv("H263MI_SPARSE_RECORDS") && getenv("H263MI_SPARSE_RECORDS")[0] == '0');
     // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
     std::vector<int> rcs(n, H263MI_OK);
     const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
@@ -1328,19 +1364,15 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
             bits::ParsedPicture &pic = b->parsed[i];
             pic.want_dense = false;                              // the coefficients travel as events
             pic.size_fits = &picture_size_fits;
+            pic.sparse_records = sparse_rec;                     // records for the coded macroblocks only (round 5)
             pic.mbs_ext = g2.h_mbs + (size_t)i * per;
             pic.mbs_ext_cap = per;
             int rc = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
             if (rc == H263MI_OK && (pic.desc.width != b->L.width || pic.desc.height != b->L.height)) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;
-            if (rc == H263MI_OK && !(b->ss[i].has_ref && b->ss[i].cur >= 0)) {
-                // gather.rs:149: an inter macroblock without a reference picture is Error::UncodedIFrameBlocks -- found
-                // here, before anything is queued, so that the stream (parser state included) stays as it was
-                const h263mi_mb_record *r = pic.records();
-                for (size_t k = 0, e = pic.n_records(); k < e; k++)
-                    if (mb_is_inter(r[k].mb_type)) { rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS; break; }
-                // (macroblocks the picture does not code are padded as Inter, state.rs:421-427)
-                if (rc == H263MI_OK && pic.n_records() < per) rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS;
-            }
+            // gather.rs:149: an inter macroblock without a reference picture is Error::UncodedIFrameBlocks -- found here,
+            // before anything is queued, so that the stream (parser state included) stays as it was (macroblocks the picture
+            // does not code are padded as Inter, state.rs:421-427: the parser's any_inter covers them)
+            if (rc == H263MI_OK && !(b->ss[i].has_ref && b->ss[i].cur >= 0) && pic.any_inter) rc = H263MI_ERR_UNCODED_IFRAME_BLOCKS;
             rcs[i] = rc;
         });
     };
@@ -1371,7 +1403,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         for (uint32_t i = 0; i < n; i++) consumed[i] = 0;
     if (!n_ok) return first_error;
     std::vector<const h263mi_mb_record *> mbs(n);
-    std::vector<const uint32_t *> first(n), events(n);
+    std::vector<const uint32_t *> first(n), events(n), gidx(n, nullptr);
     std::vector<uint32_t> n_mbs(n, 0), n_blocks(n, 0), n_events(n, 0);
     static const uint32_t kNoEvents[1] = {0};
     for (uint32_t i = 0; i < n; i++) {
@@ -1382,6 +1414,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         if (!takes_part[i]) continue;
         mbs[i] = pic.records();
         n_mbs[i] = (uint32_t)pic.n_records();
+        gidx[i] = pic.group_index.data();
         first[i] = pic.block_first_event.data();
         events[i] = pic.events.data();
         n_blocks[i] = (uint32_t)pic.n_coded_blocks;
@@ -1395,7 +1428,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     }
     const bool deferred = b->pipeline_post && (d_rgba || d_deblocked);
     int rc = batch_submit_host(b, H263MI_PICTURE_P, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
-                               n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred);
+                               n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred, sparse_rec ? gidx.data() : nullptr);
     int render_rc = H263MI_OK;
     if (rc == H263MI_OK) {
         // the pictures are decoded: what the streams remember of their headers moves on with them, whatever happens to the

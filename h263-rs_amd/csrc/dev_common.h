@@ -135,6 +135,15 @@ struct ReconArgs {
     uint32_t bands;              // k_recon: XCDs that share one picture (8 or 4; set by the launcher, see launch_frame)
     uint32_t n_events;           // sparse transport: words in `events` (0xffffffff: the caller did not say) -- a block whose
                                  // bounds are not ascending or reach beyond it is not read and the picture is rejected
+    // SPARSE RECORDS (round 5; the batch entry that parses bitstreams on the host): `mbs` holds records for the macroblocks that
+    // are coded only.  mb_group_index[pic * groups_per_picture + mby * tiles_x + mbx0 / 8] = first << 8 | mask for the 8
+    // macroblocks a reconstruction wave works on: bit k of mask = macroblock k has a record, `first` = the number of its first
+    // record counted from the picture's first (mb_base[pic], in records).  A macroblock without a record is not coded (INTER,
+    // zero vectors, nothing coded: state.rs:207-216).  nullptr: `mbs` is the dense raster array.
+    const uint32_t *mb_group_index;
+    const uint64_t *mb_base;
+    uint32_t groups_per_picture;
+    uint32_t pad_;
 };
 
 // ---------------------------------------------------------------------------

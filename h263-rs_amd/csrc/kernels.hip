@@ -101,7 +101,8 @@ __device__ __forceinline__ PrefetchTokens recon_prefetch(const ReconArgs &a, con
 {
     PrefetchTokens k = {{0u, 0u, 0u}, 0u, 0u, 0u, 0ull, false};
 #if !defined(H263MI_NO_PREFETCH)
-    if (wave_exists(a, plan.far)) {                             // uniform
+    // (sparse records: where a later wave's records are is written in ITS index word -- two dependent accesses; not prefetched)
+    if (!a.mb_group_index && wave_exists(a, plan.far)) {        // uniform
         const WavePos &q = plan.far;
         const int n = (int)a.L.mbw - q.mbx0;                    // records of that wave: min(n, 8)
         const ScalarPtr32 r = (ScalarPtr32)(uintptr_t)(a.mbs + (size_t)q.pic * a.mbs_per_picture + (size_t)q.mby * a.L.mbw + q.mbx0);
@@ -323,7 +324,14 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     unsigned long long t_prev_ = 0;
 #endif
     ISA_MARK("prologue_end");
-    recon_phase_load(a, s, lane, p);
+    const uint32_t group_word = recon_group_word(a, p);       // (sparse records: which macroblocks of the wave have one)
+    if (a.mb_group_index && (group_word & 0xffu) == 0 && a.has_ref && recon_valid_mask(a, p) == 0xffu) {
+        // sparse records: none of the eight macroblocks has a record = none is coded: the copy path, without ever touching a
+        // record (the dense form reads 256 bytes of records and runs the mark phase to find that out)
+        recon_phase_copy(a, lane, p);
+        return;
+    }
+    recon_phase_load(a, s, lane, p, group_word);
     ISA_MARK("load_end");
     PHASE_MARK(0);                                  // records requested and in LDS
     // `ln`: the lane index behind an opaque asm, re-derived per phase so that lane-only expressions are

@@ -462,8 +462,34 @@ H263_DEV uint32_t recon_block_limit(const ReconArgs &a, const WavePos &p)
     return (hi || lo > (1u << 25)) ? (1u << 25) : lo;
 }
 
-H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p)
+// the wave's word of the sparse record index (ReconArgs::mb_group_index), 0 when the records are dense: wave-uniform
+H263_DEV uint32_t recon_group_word(const ReconArgs &a, const WavePos &p)
 {
+    if (!a.mb_group_index) return 0u;
+    return a.mb_group_index[(size_t)p.pic * a.groups_per_picture + (size_t)p.mby * a.tiles_x + (size_t)(p.mbx0 >> 3)];
+}
+
+H263_DEV void recon_phase_load(const ReconArgs &a, ReconWave &s, int lane, const WavePos &p, uint32_t group_word = 0)
+{
+    if (a.mb_group_index) {
+        // sparse records: macroblock m of the wave has a record when bit m of the group word is set -- the (number of set
+        // bits below m)-th behind the group's first --, else it is not coded: INTER, quantiser 1 (never used), all else zero
+        if (lane < TILE_MBX * 2) {
+            const int m = lane >> 1, part = lane & 1;
+            const uint32_t mask = group_word & 0xffu;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p.mbx0 + m < (int)a.L.mbw && p.mby < (int)a.L.mbh) {
+                if ((mask >> m) & 1u) {
+                    const size_t k = (size_t)(group_word >> 8) + (size_t)popc32(mask & ((1u << m) - 1u));
+                    v = reinterpret_cast<const uint4 *>(a.mbs + a.mb_base[p.pic] + k)[part];
+                } else if (part == 0) {
+                    v.x = (uint32_t)H263MI_MB_INTER | (1u << 8);
+                }
+            }
+            reinterpret_cast<uint4 *>(&s.rec[m][0])[part] = v;
+        }
+        return;
+    }
     if (lane < TILE_MBX * 2) {
         // 16 lanes x 16 B = the 8 records of this macroblock row segment (one 256-B run)
         const int m = lane >> 1, part = lane & 1;

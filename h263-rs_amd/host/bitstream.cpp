@@ -929,6 +929,7 @@ int decode_picture_header(BitReader &r, uint32_t decoder_options, const ParserCo
 // ---------------------------------------------------------------------------------------------------
 namespace {
 struct Mv { int16_t x, y; };
+inline bool mb_type_is_inter(uint32_t t) { return t == H263MI_MB_INTER || t == H263MI_MB_INTER_Q || t == H263MI_MB_INTER4V || t == H263MI_MB_INTER4V_Q; }
 
 // HalfPel::median_of (types.rs:772-800): the reference's comparison chain returns the median of the three; here as
 // min / max (no data-dependent branches: the vectors of a P picture are as good as random to a branch predictor)
@@ -1078,6 +1079,14 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     // the records go to the caller's array when it can hold the picture, else into out.mbs
     const bool ext = out.mbs_ext != nullptr && total <= out.mbs_ext_cap;
     out.mbs_ext_used = ext;
+    // sparse records (ParsedPicture::sparse_records): no record for a macroblock that is not coded, a word per group of 8
+    const bool sparse_rec = out.sparse_records;
+    const size_t groups_per_line = (mb_per_line + 7) / 8;
+    out.group_index.clear();
+    if (sparse_rec) out.group_index.assign(groups_per_line * mb_height, 0u);
+    uint32_t *const group_index = out.group_index.data();
+    size_t n_rec = 0;                                // records written (== n_mbs unless sparse)
+    bool any_inter = false;
     // (no zero-fill of the record array: a record is assembled in registers and stored whole, 32 bytes, when its macroblock
     // is done -- round 3 cleared 261 KB per 1080p picture first and then wrote most of it again)
     if (!ext) out.mbs.resize(total);
@@ -1108,8 +1117,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
 #if H263MI_STREAM_RECORDS
         _mm_sfence();
 #endif
-        if (ext) out.n_mbs_ext = n_mbs < total ? n_mbs : total;
-        else out.mbs.resize(n_mbs);
+        out.n_macroblocks = n_mbs < total ? n_mbs : total;
+        out.any_inter = any_inter || n_mbs < total;      // (macroblocks the bitstream does not reach are padded as Inter, state.rs:421-427)
+        if (ext) out.n_mbs_ext = sparse_rec ? n_rec : (n_mbs < total ? n_mbs : total);
+        else out.mbs.resize(sparse_rec ? n_rec : n_mbs);
         out.block_first_event.resize(n_blocks + 1);
         out.events.resize(n_events);
         out.n_coded_blocks = n_blocks;
@@ -1162,7 +1173,9 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                     h263mi_mb_record skipped{};
                     skipped.mb_type = H263MI_MB_INTER;
                     skipped.quant = (uint8_t)(in_force_quantizer < 1 ? 1 : in_force_quantizer);
-                    for (size_t k = 0; k < run; k++) store_record(recs + n_mbs + k, skipped);
+                    if (!sparse_rec)
+                        for (size_t k = 0; k < run; k++) store_record(recs + n_mbs + k, skipped);
+                    any_inter = true;
                     n_mbs += run;
                     // zero vectors for the run, row segment by row segment of the two-row ring
                     for (size_t left = run; left;) {
@@ -1445,7 +1458,17 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             rec.mv[k][1] = motion_vectors[k].y;
             pv_at(mb_line, mb_col)[k] = motion_vectors[k];
         }
-        store_record(recs + n_mbs, rec);
+        any_inter = any_inter || mb_type_is_inter(rec.mb_type);
+        if (!sparse_rec) {
+            store_record(recs + n_mbs, rec);
+        } else if (!uncoded) {
+            // (a macroblock that is not coded has no record: that is what the absence of one says)
+            uint32_t &gw = group_index[mb_line * groups_per_line + (mb_col >> 3)];
+            if (!(gw & 0xffu)) gw = (uint32_t)n_rec << 8;
+            gw |= 1u << (mb_col & 7);
+            store_record(recs + n_rec, rec);
+            n_rec++;
+        }
         n_mbs++;
         if (++mb_col == mb_per_line) { mb_col = 0; mb_line++; }
     }

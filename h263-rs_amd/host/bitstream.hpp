@@ -217,9 +217,11 @@ struct DefaultInitAlloc : std::allocator<T> {
 typedef std::vector<uint32_t, DefaultInitAlloc<uint32_t>> WordBuffer;
 
 // ---- whole picture -> records (state.rs:138-427) ------------------------------------------------------
+typedef std::vector<h263mi_mb_record, DefaultInitAlloc<h263mi_mb_record>> RecordBuffer;
+
 struct ParsedPicture {
     h263mi_picture_desc desc{};
-    std::vector<h263mi_mb_record> mbs;     // the macroblocks present in the bitstream (<= mbw*mbh)
+    RecordBuffer mbs;                      // the macroblocks present in the bitstream (<= mbw*mbh); see sparse_records
     // Optional destination of the records (set before parsing; e.g. a slot of pinned staging memory): when the picture
     // has at most mbs_ext_cap macroblocks the records are written there instead of into `mbs` (which stays empty), and
     // n_mbs_ext says how many.  A picture with more macroblocks than that uses `mbs` as usual (mbs_ext_used = false).
@@ -232,6 +234,19 @@ struct ParsedPicture {
     // the same coefficients as events, level << 16 | raster position, block k = [block_first_event[k], [k+1])
     WordBuffer block_first_event, events;
     bool want_dense = true;                // set to false before parsing to skip the dense blocks
+    // SPARSE RECORDS (round 5; set before parsing): two thirds of the macroblocks of a real P
+    // picture are not coded (COD = 1: INTER, zero vectors, nothing coded, state.rs:207-216) and their 32-byte records say
+    // nothing -- 177 of the 261 KB a 1080p picture sends over the link.  With this set, records() holds the records of the OTHER
+    // macroblocks only, in raster order, and `group_index` one word per group of 8 macroblocks of a row (the unit a
+    // reconstruction wave works on; groups per row = ceil(mbw / 8)): first << 8 | mask -- bit k of `mask`: macroblock k of the
+    // group has a record, `first`: the number of its first record in records().  A macroblock without a record is not coded.
+    // (Macroblocks the bitstream does not reach have none either: they are padded as not coded, state.rs:421-427.)
+    bool sparse_records = false;
+    WordBuffer group_index;
+    size_t n_macroblocks = 0;              // macroblocks the bitstream held (records + the ones without one)
+    // some macroblock takes a prediction (inter type, not coded, or not reached by the bitstream): the picture needs a
+    // reference picture (gather.rs:149).  Set by the parser in every mode.
+    bool any_inter = false;
     // The caller's limit on the picture size (null = none), asked right behind the header -- before any of the arrays below is
     // sized for the picture: a Sorenson custom format carries 16-bit dimensions out of an untrusted bitstream, and 65 535 x
     // 65 535 is 16.7 M macroblocks (1.2 GB of records, vectors and block offsets) whether or not any data follows.  A picture

@@ -236,6 +236,45 @@ const char *check_structure(const ParsedPicture &p, uint32_t options)
     return nullptr;
 }
 
+// ParsedPicture::sparse_records against the dense records of the same input: a macroblock with a record has that record; one
+// without is "not coded" in the dense array (INTER, nothing coded, zero vectors: state.rs:207-216; its quantiser -- never
+// used -- is the one field the sparse form does not carry); `first` of every group = the number of records in front of it
+const char *check_sparse(const ParsedPicture &dense, const ParsedPicture &sp)
+{
+    const size_t mbw = (dense.desc.width + 15) / 16, mbh = (dense.desc.height + 15) / 16, gpl = (mbw + 7) / 8;
+    if (sp.group_index.size() != gpl * mbh) return "group index of the wrong size";
+    if (sp.n_macroblocks != dense.n_records()) return "sparse: macroblock count differs";
+    if (sp.any_inter != dense.any_inter) return "sparse: any_inter differs";
+    const h263mi_mb_record *d = dense.records();
+    size_t k = 0;
+    for (size_t line = 0; line < mbh; line++)
+        for (size_t g = 0; g < gpl; g++) {
+            const uint32_t gw = sp.group_index[line * gpl + g];
+            if ((gw & 0xffu) && (gw >> 8) != k) return "sparse: `first` of a group is not the number of records in front of it";
+            for (size_t b = 0; b < 8; b++) {
+                const size_t col = g * 8 + b, mb = line * mbw + col;
+                const bool has = (gw >> b) & 1u;
+                if (col >= mbw || mb >= dense.n_records()) {
+                    if (has) return "sparse: a record for a macroblock the bitstream does not hold";
+                    continue;
+                }
+                if (has) {
+                    if (k >= sp.n_records()) return "sparse: more mask bits than records";
+                    if (memcmp(&sp.records()[k], &d[mb], sizeof(h263mi_mb_record))) return "sparse: a record differs from the dense one";
+                    k++;
+                } else {
+                    h263mi_mb_record skip{};
+                    skip.mb_type = H263MI_MB_INTER;
+                    skip.quant = d[mb].quant;
+                    if (memcmp(&skip, &d[mb], sizeof skip)) return "sparse: a macroblock without a record is coded in the dense form";
+                }
+            }
+        }
+    if (k != sp.n_records()) return "sparse: records nobody points at";
+    if (sp.events != dense.events || sp.block_first_event != dense.block_first_event) return "sparse: events differ";
+    return nullptr;
+}
+
 struct Stats {
     std::atomic<uint64_t> inputs{0}, parsed_ok{0}, layer_checks{0};
     std::atomic<uint64_t> rc_hist[32];
@@ -245,7 +284,7 @@ struct Stats {
 struct Worker {
     const std::vector<Seed> &corpus;
     Stats &st;
-    ParsedPicture reused_fast, reused_field;      // live across inputs, like the product's per-stream buffers
+    ParsedPicture reused_fast, reused_field, reused_sparse;      // live across inputs, like the product's per-stream buffers
     Worker(const std::vector<Seed> &c, Stats &s) : corpus(c), st(s) {}
 
     void one_input(uint64_t index, uint64_t base_seed)
@@ -286,6 +325,29 @@ struct Worker {
             if (!same_pictures(fresh_fast, reused_fast, why) || !same_pictures(fresh_fast, reused_field, why))
                 report("a reused ParsedPicture gives other outputs than a fresh one", d, options, index);
             if (const char *bad = check_structure(fresh_fast, options)) report(bad, d, options, index);
+            {
+                // the sparse record form (what the batch entry sends over the link) against the dense one
+                ParsedPicture sp;
+                sp.want_dense = false;
+                sp.size_fits = &fits_small;
+                sp.sparse_records = true;
+                if (parse_picture(data, len, options, nullptr, sp) != ra) report("sparse records: another return code", d, options, index);
+                if (const char *bad = check_sparse(fresh_fast, sp)) report(bad, d, options, index);
+                // ... and with a reused object, as the product's per-stream buffers are
+                // ... into the caller's array (the smallest legal one: the batch entry's staging slot), with a reused object
+                const size_t total_mbs = (size_t)((fresh_fast.desc.width + 15) / 16) * ((fresh_fast.desc.height + 15) / 16);
+                h263mi_mb_record *slot = (h263mi_mb_record *)malloc((total_mbs ? total_mbs : 1) * sizeof(h263mi_mb_record));
+                reused_sparse.want_dense = false;
+                reused_sparse.size_fits = &fits_small;
+                reused_sparse.sparse_records = true;
+                reused_sparse.mbs_ext = slot;
+                reused_sparse.mbs_ext_cap = total_mbs;
+                if (parse_picture(data, len, options, nullptr, reused_sparse) != ra) report("sparse records (reused): another return code", d, options, index);
+                if (!reused_sparse.mbs_ext_used) report("sparse records: the caller's array was not used", d, options, index);
+                if (const char *bad = check_sparse(fresh_fast, reused_sparse)) report(bad, d, options, index);
+                reused_sparse.mbs_ext = nullptr;
+                free(slot);
+            }
             if (fresh_fast.bits_consumed > len * 8) report("more bits consumed than there are", d, options, index);
             // in-place record writer: the smallest legal slot, and one record less
             const size_t total = (size_t)((fresh_fast.desc.width + 15) / 16) * ((fresh_fast.desc.height + 15) / 16);

@@ -73,11 +73,20 @@ void sim_force_wide_rounds(int on) { force_wide_rounds = on; }
 void sim_layout(uint32_t w, uint32_t h, FrameLayout *out) { *out = make_layout(w, h); }
 
 // block_first_event / events: sparse coefficient transport consumed by the reconstruction wave itself (nullptr: dense)
+// sparse records (ReconArgs::mb_group_index): set before a sim_recon_ex call, used by it, cleared behind it
+static const uint32_t *g_group_index = nullptr;
+static const uint64_t *g_mb_base = nullptr;
+void sim_set_sparse_records(const uint32_t *group_index, const uint64_t *mb_base) { g_group_index = group_index; g_mb_base = mb_base; }
+
 int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, const int16_t *coeffs,
                  uint64_t n_blocks, const uint64_t *coeff_base, const uint8_t *ref, int has_ref, uint8_t *cur,
                  uint32_t *status, const uint32_t *block_first_event, const uint32_t *events)
 {
     ReconArgs a{};
+    a.mb_group_index = g_group_index;
+    a.mb_base = g_mb_base;
+    g_group_index = nullptr;
+    g_mb_base = nullptr;
     a.L = make_layout(w, h);
     a.mbs = mbs;
     a.coeffs = coeffs;
@@ -95,6 +104,7 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
     a.has_ref = has_ref;
     a.tiles_x = (a.L.mbw + TILE_MBX - 1) / TILE_MBX;
     a.tiles_y = (a.L.mbh + TILE_MBY - 1) / TILE_MBY;
+    a.groups_per_picture = a.tiles_x * a.L.mbh;
     ReconWave *s = (ReconWave *)aligned_alloc(16, (sizeof(ReconWave) + 15) / 16 * 16);
     // same work units as kernels.hip::k_recon: XCD-ordered tiles, one independent wave per macroblock row of a tile (the
     // order of units does not matter)
@@ -112,7 +122,12 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
             if (p.mby >= (int)a.L.mbh) continue;
             p.cbase = a.coeff_base ? a.coeff_base[p.pic] : 0ull;
             memset(s, 0xA5, sizeof *s);   // LDS is not zero-initialised on the device either
-            for (int l = 0; l < 64; l++) recon_phase_load(a, *s, l, p);
+            const uint32_t group_word = recon_group_word(a, p);
+            if (a.mb_group_index && (group_word & 0xffu) == 0 && a.has_ref && recon_valid_mask(a, p) == 0xffu) {   // as kernels.hip::recon_wave
+                for (int l = 0; l < 64; l++) recon_phase_copy(a, l, p);
+                continue;
+            }
+            for (int l = 0; l < 64; l++) recon_phase_load(a, *s, l, p, group_word);
             WaveMasks km;
             km.valid = recon_valid_mask(a, p);
             km.act = 0;

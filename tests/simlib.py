@@ -78,11 +78,40 @@ def pad_records(mbs, w, h):
     return out
 
 
-def recon(w, h, mbs, coeffs, ref=None, asan=False, events=False):
+def to_sparse_records(mbs, w, h):
+    """dense raster records -> (records of the macroblocks that are coded, group index) of ReconArgs::mb_group_index: a
+    macroblock that is not coded (INTER, no vector, nothing coded) has no record; one word per group of 8 macroblocks of a row"""
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    gpl = (mbw + 7) // 8
+    index = np.zeros(gpl * mbh, np.uint32)
+    keep = []
+    for k in range(len(mbs)):
+        m = mbs[k]
+        if int(m["mb_type"]) == 0 and int(m["cbp"]) == 0 and not np.asarray(m["mv"]).any():
+            continue
+        line, col = divmod(k, mbw)
+        g = line * gpl + col // 8
+        if not index[g] & 0xff:
+            index[g] = len(keep) << 8
+        index[g] |= 1 << (col % 8)
+        keep.append(k)
+    return np.ascontiguousarray(mbs[keep]), index
+
+
+def recon(w, h, mbs, coeffs, ref=None, asan=False, events=False, sparse_records=False):
     """One picture through the kernel phases on the CPU.  Returns (status, (y, cb, cr)).  events: the coefficients reach
     the reconstruction wave as sparse events (block_first_event + events), not as dense blocks."""
     L = layout(w, h)
     mbs = pad_records(mbs, w, h)
+    keep_alive = None
+    if sparse_records:
+        mbs, gi = to_sparse_records(mbs, w, h)
+        if len(mbs) == 0:
+            mbs = np.zeros(1, mbs.dtype)
+        base = np.zeros(1, np.uint64)
+        keep_alive = (gi, base)
+        lib(asan).sim_set_sparse_records.argtypes = [C.c_void_p, C.c_void_p]
+        lib(asan).sim_set_sparse_records(_p(gi), _p(base))
     coeffs = np.ascontiguousarray(coeffs, np.int16).reshape(-1, 64)
     if events:
         # (an intra block's DC is not an event: it travels in the record)

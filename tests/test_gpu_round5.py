@@ -348,3 +348,57 @@ def test_mixed_class_grows_by_doubling_and_shrinks_and_keeps_its_pictures(pipeli
     ch.call({s: ("P", ch.size[s]) for s in (0, 1, 3, 18)})
     ch.check("a freed slot taken again")
     ch.m.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# sparse RECORDS over the link (round 5): the batch entry that parses bitstreams sends records for the coded macroblocks only
+# plus one index word per group of 8 (ReconArgs::mb_group_index).  Every end-to-end test of the suite runs that way now; this
+# one holds the two forms against each other on content with long runs of uncoded macroblocks, whole waves of them, groups
+# with a single coded macroblock, a short picture -- and keeps the dense form (H263MI_SPARSE_RECORDS=0) covered.
+# ---------------------------------------------------------------------------------------------
+_SPARSE_PROBE = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import h263mi, recgen, sorenson_enc as enc
+from oracle import oracle as orc
+from test_bitstream_e2e import make_codable
+w, h, n, q = 352, 288, 6, 8
+b = h263mi.Batch(n, w, h, pipeline_post=True)
+d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+refs = [None] * n
+for f in range(5):
+    datas = []
+    for s in range(n):
+        if f == 0:
+            mbs, co = recgen.realistic_intra_picture(w, h, 50 + s, quant=q)
+        else:
+            mbs, co = recgen.realistic_inter_picture(w, h, 100 * f + s, p_skip=(0.3, 0.7, 0.9, 0.97, 1.0, 0.6)[s], p_coded=0.2, quant=q)
+        mbs = make_codable(mbs, q, s + f, 0 if f == 0 else 1)
+        if f == 3 and s == 1:
+            mbs = mbs[:len(mbs) - 37]                      # a picture that ends early: the rest is padded as not coded
+        datas.append(enc.encode_picture(w, h, 0 if f == 0 else 1, q, mbs, co, temporal_reference=f))
+        rc, refs[s] = orc.decode_picture(w, h, mbs, co, None if f == 0 else refs[s])
+        assert rc == 0
+    used, rcs = b.decode_next_pictures_ex(datas, n_threads=3, strength=5, d_rgba=d_rgba.ptr)
+    assert not any(rcs), rcs
+b.sync()
+for s in range(n):
+    got = b.copy_yuv(s)
+    assert all((g == e).all() for g, e in zip(got, refs[s])), s
+    cw = (w + 1) // 2
+    filt = tuple(orc.deblock(p, pw, 5) for p, pw in zip(refs[s], (w, cw, cw)))
+    assert (d_rgba.download(w * h * 4, s * w * h * 4) == orc.yuv420_to_rgba(*filt, w)).all(), s
+b.close()
+print("sparse-probe-ok")
+'''
+
+
+@pytest.mark.parametrize("sparse", ["1", "0"], ids=["sparse_records", "dense_records"])
+def test_sparse_and_dense_record_transport_decode_alike(sparse):
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    code = _SPARSE_PROBE % (root, os.path.join(root, "h263-rs_amd"), HERE)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, H263MI_SPARSE_RECORDS=sparse), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "sparse-probe-ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

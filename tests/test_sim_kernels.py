@@ -295,3 +295,30 @@ def test_dequantiser_every_level_every_quantiser_is_sixteen_times_the_clamped_va
         want = np.sign(l64) * (q * (2 * np.abs(l64) + 1) - (1 if q % 2 == 0 else 0))
         want = np.clip(want, -2048, 2047)
         assert (got == 16 * want).all(), q
+
+
+@pytest.mark.parametrize("w,h,events", [(176, 144, False), (352, 288, True), (100, 60, True), (136, 40, False)])
+def test_recon_from_sparse_records_equals_recon_from_dense_records(w, h, events):
+    """ReconArgs::mb_group_index (round 5): records for the coded macroblocks only + one index word per group of 8; a
+    macroblock without a record is not coded.  Real content -- runs of COD = 1, whole waves of them (the copy path is then
+    taken without a record being read), groups with one coded macroblock, ragged right edges -- against the oracle, and a
+    picture of nothing but uncoded macroblocks."""
+    ref = recgen.random_planes(w, h, 11)
+    for seed, p_skip in ((1, 0.7), (2, 0.95), (3, 0.3)):
+        mbs, coeffs = recgen.realistic_inter_picture(w, h, seed, p_skip=p_skip, p_coded=0.2)
+        rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+        st, got = simlib.recon(w, h, mbs, coeffs, ref, events=events, sparse_records=True)
+        assert rc == 0 and st == 0
+        for g, e, name in zip(got, want, "Y Cb Cr".split()):
+            assert (g == e).all(), (seed, name, np.flatnonzero(g != e)[:10])
+    mbs, coeffs = recgen.realistic_inter_picture(w, h, 4, p_skip=1.0, p_coded=0.0)
+    st, got = simlib.recon(w, h, mbs, coeffs, ref, events=events, sparse_records=True)
+    assert st == 0 and all((g == e).all() for g, e in zip(got, ref))
+    # an inter picture without a reference is still an error (gather.rs:149), also when nothing has a record
+    st, _ = simlib.recon(w, h, mbs, coeffs, None, events=events, sparse_records=True)
+    assert st & 1
+    # intra macroblocks in the mix, a short picture (macroblocks the bitstream does not reach have no record either)
+    mbs, coeffs = recgen.inter_picture(w, h, seed=9, mv_range=20, p_4v=0.2, p_intra=0.2, p_coded=0.4, n_mbs=max(1, ((w + 15) // 16) * ((h + 15) // 16) - 5))
+    rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
+    st, got = simlib.recon(w, h, mbs, coeffs, ref, events=events, sparse_records=True)
+    assert rc == 0 and st == 0 and all((g == e).all() for g, e in zip(got, want))

@@ -309,10 +309,16 @@ struct h263mi_batch {
     struct HostStaging {
         MbRecord *h_mbs = nullptr, *d_mbs = nullptr;
         int16_t *h_coeffs = nullptr, *d_coeffs = nullptr;
-        uint64_t *h_base = nullptr, *d_base = nullptr;       // [0, n): coefficient base per stream; [n, 2n): record base (sparse records)
-        uint32_t *h_index = nullptr, *d_index = nullptr;     // sparse records: one word per group of 8 macroblocks, stream after stream
-        uint32_t *h_events = nullptr, *d_events = nullptr;   // sparse transport: rebased block offsets, then events
-        size_t cap_blocks = 0, cap_events = 0;
+        // ONE buffer (pinned host + device) for everything small that goes with a call, so that it crosses the link in one copy:
+        // [base: 2n x u64 -- [0, n) coefficient base per stream, [n, 2n) record base (sparse records)]
+        // [index: n x groups per picture x u32 -- sparse records, one word per group of 8 macroblocks]
+        // [events: rebased block offsets, then the events -- sparse coefficient transport]
+        uint32_t *h_words = nullptr, *d_words = nullptr;
+        size_t cap_words = 0;
+        uint64_t *h_base = nullptr, *d_base = nullptr;       // (into h_words / d_words)
+        uint32_t *h_index = nullptr, *d_index = nullptr;
+        uint32_t *h_events = nullptr, *d_events = nullptr;
+        size_t cap_blocks = 0;
         hipEvent_t done = nullptr;             // recorded after the kernel that reads the slot
     } host_stg[2];
     unsigned host_slot = 0;
@@ -508,12 +514,8 @@ struct h263mi_batch {
             if (g2.d_mbs) (void)hipFree(g2.d_mbs);
             if (g2.h_coeffs) (void)hipHostFree(g2.h_coeffs);
             if (g2.d_coeffs) (void)hipFree(g2.d_coeffs);
-            if (g2.h_base) (void)hipHostFree(g2.h_base);
-            if (g2.d_base) (void)hipFree(g2.d_base);
-            if (g2.h_index) (void)hipHostFree(g2.h_index);
-            if (g2.d_index) (void)hipFree(g2.d_index);
-            if (g2.h_events) (void)hipHostFree(g2.h_events);
-            if (g2.d_events) (void)hipFree(g2.d_events);
+            if (g2.h_words) (void)hipHostFree(g2.h_words);
+            if (g2.d_words) (void)hipFree(g2.d_words);
             if (g2.done) (void)hipEventDestroy(g2.done);
         }
     }
@@ -526,26 +528,27 @@ struct h263mi_batch {
         // each piece on its own, so that a failed allocation leaves nothing half-initialised for the next call
         if (!g2.h_mbs) HIP_TRY(hipHostMalloc((void **)&g2.h_mbs, total * sizeof(MbRecord), hipHostMallocDefault));
         if (!g2.d_mbs) HIP_TRY(hipMalloc((void **)&g2.d_mbs, total * sizeof(MbRecord)));
-        if (!g2.h_base) HIP_TRY(hipHostMalloc((void **)&g2.h_base, 2 * (size_t)n * sizeof(uint64_t), hipHostMallocDefault));
-        if (!g2.d_base) HIP_TRY(hipMalloc((void **)&g2.d_base, 2 * (size_t)n * sizeof(uint64_t)));
-        const size_t index_words = (size_t)n * recon_tiles_x(L) * L.mbh;
-        if (!g2.h_index) HIP_TRY(hipHostMalloc((void **)&g2.h_index, index_words * sizeof(uint32_t), hipHostMallocDefault));
-        if (!g2.d_index) HIP_TRY(hipMalloc((void **)&g2.d_index, index_words * sizeof(uint32_t)));
         if (!g2.done) HIP_TRY(hipEventCreateWithFlags(&g2.done, hipEventDisableTiming));
         return H263MI_OK;
     }
 
+    // words in front of the events in HostStaging::h_words: the two base arrays and the sparse-record index
+    size_t head_words() const { return 4 * (size_t)n + (size_t)n * recon_tiles_x(L) * L.mbh; }
     int ensure_host_staging(HostStaging &g2, size_t n_blocks, size_t n_event_words = 0)
     {
-        if (n_event_words > g2.cap_events) {
-            if (g2.h_events) (void)hipHostFree(g2.h_events);
-            if (g2.d_events) (void)hipFree(g2.d_events);
-            g2.h_events = nullptr; g2.d_events = nullptr; g2.cap_events = 0;
-            const size_t cap = n_event_words + n_event_words / 2 + 256;
-            HIP_TRY(hipHostMalloc((void **)&g2.h_events, cap * sizeof(uint32_t), hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&g2.d_events, cap * sizeof(uint32_t)));
-            g2.cap_events = cap;
+        const size_t head = head_words();
+        if (head + n_event_words > g2.cap_words) {
+            if (g2.h_words) (void)hipHostFree(g2.h_words);
+            if (g2.d_words) (void)hipFree(g2.d_words);
+            g2.h_words = nullptr; g2.d_words = nullptr; g2.cap_words = 0;
+            const size_t cap = head + n_event_words + n_event_words / 2 + 256;
+            HIP_TRY(hipHostMalloc((void **)&g2.h_words, cap * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&g2.d_words, cap * sizeof(uint32_t)));
+            g2.cap_words = cap;
         }
+        g2.h_base = reinterpret_cast<uint64_t *>(g2.h_words);  g2.d_base = reinterpret_cast<uint64_t *>(g2.d_words);
+        g2.h_index = g2.h_words + 4 * (size_t)n;               g2.d_index = g2.d_words + 4 * (size_t)n;
+        g2.h_events = g2.h_words + head;                       g2.d_events = g2.d_words + head;
         RC_TRY(ensure_record_staging(g2));
         // with sparse transport there are no dense blocks anywhere: the reconstruction waves read the events
         if (!n_event_words && (n_blocks > g2.cap_blocks || !g2.h_coeffs)) {
@@ -1206,11 +1209,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     hipStream_t cs = b->stream;
     const auto enqueue_copies = [&]() -> int {
         if (sparse_rec) {
-            // sparse records: the head of every stream's part in one 2-D copy, the index words in another
+            // sparse records: the head of every stream's part in one 2-D copy (the index words travel with the small things below)
             if (records_sent)
                 HIP_TRY(hipMemcpy2DAsync(g2.d_mbs, per * sizeof(MbRecord), g2.h_mbs, per * sizeof(MbRecord), records_sent * sizeof(MbRecord),
                                          b->n, hipMemcpyHostToDevice, cs));
-            HIP_TRY(hipMemcpyAsync(g2.d_index, g2.h_index, (size_t)b->n * groups_pp * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         }
         // the records of the streams that take part, one copy per run of neighbouring streams (all of them: one copy)
         for (uint32_t i = 0; i < b->n && !sparse_rec;) {
@@ -1221,11 +1223,11 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                                    hipMemcpyHostToDevice, cs));
             i = j;
         }
-        HIP_TRY(hipMemcpyAsync(g2.d_base, g2.h_base, 2 * (size_t)b->n * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
-        if (sparse && blocks) {
-            h_first[blocks] = (uint32_t)n_ev;
-            HIP_TRY(hipMemcpyAsync(g2.d_events, g2.h_events, event_words * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
-        } else if (blocks) {
+        // the bases, the record index and the events: one copy (HostStaging::h_words)
+        if (sparse && blocks) h_first[blocks] = (uint32_t)n_ev;
+        HIP_TRY(hipMemcpyAsync(g2.d_words, g2.h_words, (b->head_words() + (sparse && blocks ? event_words : 0)) * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, cs));
+        if (!sparse && blocks) {
             HIP_TRY(hipMemcpyAsync(g2.d_coeffs, g2.h_coeffs, blocks * 128, hipMemcpyHostToDevice, cs));
         }
         return H263MI_OK;

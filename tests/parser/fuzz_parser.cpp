@@ -14,7 +14,9 @@
 //   * a ParsedPicture that is REUSED from input to input, the way the product's per-stream parse buffers are, against a
 //     fresh one;
 //   * the input in a heap block of exactly its size (the windows read ahead of the cursor: a read past the end is an ASan
-//     report).
+//     report);
+//   * the SPARSE record form (ParsedPicture::sparse_records: records for the coded macroblocks only + an index word per
+//     group of 8), into the parser's own array and in place into an exactly sized external one, against the dense records.
 //
 // and asserts on every input that still parses (rc == H263MI_OK):
 //   * structure: macroblock count <= the picture's, known types, quantisers 1..31, kill within cbp, coeff_index = running

@@ -335,7 +335,7 @@ struct h263mi_batch {
     // H263MI_TRACE_E2E=1: where the host time of h263mi_batch_decode_next_pictures goes (printed when the batch is
     // destroyed): [0] parser threads, [1] waiting for the staging slot, [2] packing into pinned staging, [3] enqueueing
     // copies and launches
-    double host_ms[4] = {0, 0, 0, 0};
+    double host_ms[6] = {0, 0, 0, 0, 0, 0};     // ... [4] of [3]: the copies, [5] of [3]: submit (state words, launch)
     size_t frame_skew = 0;
     unsigned host_calls = 0;
     bool trace_host = getenv("H263MI_TRACE_E2E") != nullptr;
@@ -491,8 +491,8 @@ struct h263mi_batch {
         (void)hipStreamSynchronize(stream);
         if (trace_host && host_calls)
             fprintf(stderr, "h263mi batch (%u streams): %u host submits; ms per call: parse %.3f, wait for slot %.3f, pack %.3f, "
-                            "enqueue %.3f\n", n, host_calls, host_ms[0] / host_calls, host_ms[1] / host_calls,
-                    host_ms[2] / host_calls, host_ms[3] / host_calls);
+                            "enqueue %.3f (copies %.3f, launch %.3f)\n", n, host_calls, host_ms[0] / host_calls, host_ms[1] / host_calls,
+                    host_ms[2] / host_calls, host_ms[3] / host_calls, host_ms[4] / host_calls, host_ms[5] / host_calls);
         release_frames();
         if (post_stream) {
             (void)hipStreamSynchronize(post_stream);
@@ -1098,7 +1098,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     // group_index (from the parser only): SPARSE RECORDS -- mbs[i] holds the n_mbs[i] records of stream i's coded macroblocks
     // (written in place at the head of the stream's part of the staging slot) and group_index[i] one word per group of 8
     // macroblocks (bits::ParsedPicture::sparse_records, ReconArgs::mb_group_index): what crosses the link is the head of every
-    // stream's part, as long as the longest of them -- one 2-D copy; a third of the bytes of the dense arrays on real content
+    // stream's part, as long as the longest of them -- one 2-D copy; a third of the bytes of the dense arrays on real content.
+    // (Packing the streams' records one behind the other for a plain copy was measured too: the 2-D copy costs 0.08 ms more of
+    // host time to enqueue, the packing pass 0.05 ms and the parser its non-temporal stores -- the call as a whole 0.45 -> 0.48 ms;
+    // profiles/r05_j_e2e_per_call_packed_records.txt.)
     const bool sparse_rec = group_index != nullptr && from_parser;
     // from_parser: the arrays are what bits::parse_picture just wrote (h263mi_batch_decode_next_pictures) -- valid by
     // construction, so the per-record checks a caller's arrays get are skipped; pack_threads: the caller's thread budget
@@ -1234,6 +1237,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     };
     {
         const int crc = enqueue_copies();
+        if (b->trace_host) b->host_ms[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
         if (crc != H263MI_OK) {
             // nothing is launched: no copy may still be reading this slot's host memory when a later call fills it again
             (void)hipStreamSynchronize(cs);
@@ -1254,7 +1258,9 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         b->cur_mb_base = g2.d_base + b->n;
     }
     {
+        const auto t_sub0 = std::chrono::steady_clock::now();
         const int src = b->submit(picture_type, g2.d_mbs, g2.d_coeffs, g2.d_base, /*with_post=*/deferred_post && b->pending.valid, types);
+        if (b->trace_host) b->host_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sub0).count();
         if (src != H263MI_OK) {
             (void)hipStreamSynchronize(cs);      // (no copy left behind that reads this slot)
             return src;

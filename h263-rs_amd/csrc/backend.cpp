@@ -1099,9 +1099,11 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     // (written in place at the head of the stream's part of the staging slot) and group_index[i] one word per group of 8
     // macroblocks (bits::ParsedPicture::sparse_records, ReconArgs::mb_group_index): what crosses the link is the head of every
     // stream's part, as long as the longest of them -- one 2-D copy; a third of the bytes of the dense arrays on real content.
-    // (Packing the streams' records one behind the other for a plain copy was measured too: the 2-D copy costs 0.08 ms more of
-    // host time to enqueue, the packing pass 0.05 ms and the parser its non-temporal stores -- the call as a whole 0.45 -> 0.48 ms;
-    // profiles/r05_j_e2e_per_call_packed_records.txt.)
+    // (Packing the streams' records one behind the other for a plain copy was measured too: the call as a whole 0.45 -> 0.48 ms
+    // -- the packing pass and the parser without its non-temporal stores cost more than the plain copy saves; and so was letting
+    // the waves read the records out of the pinned slot over the link, no copy at all: +-0.  In the steady state a call IS its
+    // parse phase: 0.43-0.53 ms on 16 threads against 0.03 ms of packing and 0.01 ms of enqueueing
+    // (profiles/r05_j_e2e_per_call_packed_records.txt, r05_m_*).)
     const bool sparse_rec = group_index != nullptr && from_parser;
     // from_parser: the arrays are what bits::parse_picture just wrote (h263mi_batch_decode_next_pictures) -- valid by
     // construction, so the per-record checks a caller's arrays get are skipped; pack_threads: the caller's thread budget

@@ -221,24 +221,32 @@ H263MI_TABLE(mvd_table, kMvdCodes)
 //   mvd_pair10[10 bits]            a horizontal and a vertical MVD code word (Table 14) that lie inside 10 bits together:
 //                                  len | (dx & 63) << 4 | (dy & 63) << 10 -- the small differences of slow motion
 namespace {
-constexpr uint32_t kEventEscape = 1u << 5, kEventInvalid = 1u << 6;     // (bit 4: LAST)
+constexpr uint32_t kEventLastBit = 5, kEventEscape = 1u << 6, kEventInvalid = 1u << 7;     // (bits 0..4: bits the event takes)
 struct HeaderTables {
     uint16_t p12[4096], i12[4096], mvd10[1024];
-    // tcoef13[13 bits]: EVERY TCOEF code word (12 bits at most, Table 16/H.263) together with its sign bit, as the event it
-    // stands for: used (code + sign, 3..13) | last << 4 | run << 8 | level (signed) << 16.  ESCAPE ("0000 011") is
-    // kEventEscape, a prefix no code word starts with kEventInvalid (both with used = 0).  32 KB; what a stream touches of it
-    // are the blocks of its frequent short code words.
-    uint32_t tcoef13[8192];
+    // tcoef13[flavour][13 bits]: EVERY TCOEF code word (12 bits at most, Table 16/H.263) together with its sign bit, as the
+    // event it stands for: used (code + sign, 3..13) | last << 5 | run << 8 | level (signed) << 16.  ESCAPE ("0000 011") is
+    // kEventEscape WITH the bits the whole escape takes in `used` (22; Sorenson v1: 22 or 26 by the flag bit behind the code
+    // word, which is part of the index -- hence a table per flavour): how far the cursor moves comes straight out of the table
+    // for every kind of event, and the cursor is what the next event waits for.  A prefix no code word starts with is
+    // kEventInvalid (used = 0).  2 x 32 KB; what a stream touches are the blocks of the frequent short code words of ONE.
+    uint32_t tcoef13[2][8192];
     HeaderTables()
     {
-        for (uint32_t idx = 0; idx < 8192; idx++) {
-            const VlcTable::Slot &t = tcoef_table().lookup32(idx << 19);
-            if (!t.valid) { tcoef13[idx] = kEventInvalid; continue; }
-            if (t.v0 < 0) { tcoef13[idx] = kEventEscape; continue; }
-            const uint32_t sign = (idx >> (12 - t.len)) & 1u;
-            const int level = sign ? -(int)t.v2 : (int)t.v2;
-            tcoef13[idx] = (uint32_t)(t.len + 1) | ((uint32_t)(t.v0 != 0) << 4) | ((uint32_t)t.v1 << 8) | ((uint32_t)(uint16_t)(int16_t)level << 16);
-        }
+        for (int v1 = 0; v1 < 2; v1++)
+            for (uint32_t idx = 0; idx < 8192; idx++) {
+                const VlcTable::Slot &t = tcoef_table().lookup32(idx << 19);
+                if (!t.valid) { tcoef13[v1][idx] = kEventInvalid; continue; }
+                if (t.v0 < 0) {
+                    // ESCAPE (7 bits) [Sorenson v1: 1 bit selects an 11- or 7-bit LEVEL] LAST (1) RUN (6) LEVEL
+                    const uint32_t flag = (idx >> 5) & 1u;
+                    tcoef13[v1][idx] = kEventEscape | (v1 ? 8u + 7u + (flag ? 11u : 7u) : 7u + 7u + 8u);
+                    continue;
+                }
+                const uint32_t sign = (idx >> (12 - t.len)) & 1u;
+                const int level = sign ? -(int)t.v2 : (int)t.v2;
+                tcoef13[v1][idx] = (uint32_t)(t.len + 1) | ((uint32_t)(t.v0 != 0) << 5) | ((uint32_t)t.v1 << 8) | ((uint32_t)(uint16_t)(int16_t)level << 16);
+            }
         for (int pic = 0; pic < 2; pic++) {
             const VlcTable &mc = pic ? mcbpc_i_table() : mcbpc_p_table();
             uint16_t *out = pic ? i12 : p12;
@@ -478,14 +486,14 @@ template <bool SORENSON_V1>
 inline __attribute__((always_inline)) uint32_t event_at(uint64_t bits, const uint32_t *tcoef13, uint32_t &used)
 {
     const uint32_t e = tcoef13[bits >> 51];
+    used = e & 31u;                                                              // (the one thing the next event waits for)
     const uint32_t w = (uint32_t)(bits >> 32);
     const uint32_t e0 = SORENSON_V1 ? 8u : 7u;                                   // position of LAST
     const uint32_t width = SORENSON_V1 ? 7u + 4u * ((w >> 24) & 1u) : 8u;
     const uint32_t raw = (w >> (25u - e0 - width)) & ((1u << width) - 1u);
     const uint32_t level = (raw ^ (1u << (width - 1u))) - (1u << (width - 1u));   // two's complement of `width` bits (reader.rs:176-187)
-    const uint32_t esc_event = (((w >> (31u - e0)) & 1u) << 4) | (((w >> (25u - e0)) & 63u) << 8) | (level << 16) | kEventEscape;
-    const uint32_t m = 0u - ((e >> 5) & 1u);                                     // all ones for an ESCAPE
-    used = ((e0 + 7u + width) & m) | (e & 15u & ~m);
+    const uint32_t esc_event = (((w >> (31u - e0)) & 1u) << kEventLastBit) | (((w >> (25u - e0)) & 63u) << 8) | (level << 16) | kEventEscape;
+    const uint32_t m = 0u - ((e >> 6) & 1u);                                     // all ones for an ESCAPE
     return (esc_event & m) | (e & ~m);
 }
 
@@ -536,7 +544,7 @@ __attribute__((noinline)) InterRun inter_macroblock_events(const uint8_t *base, 
         zz += (e >> 8) & 63u;
         if (__builtin_expect(zz >= 64, 0)) return InterRun{pos, 0, H263MI_OK, false};          // rle.rs:125-127: block by block
         *out++ = (e & 0xffff0000u) | kZigzagRaster[zz];
-        const uint32_t last = (e >> 4) & 1u;
+        const uint32_t last = (e >> kEventLastBit) & 1u;
         fe[1] = events_before + (uint32_t)(out - ev);       // the block's end (rewritten until its LAST event)
         fe += last;
         zz = last ? 0u : zz + 1u;
@@ -582,7 +590,7 @@ __attribute__((noinline)) InterRun intra_macroblock_events(const uint8_t *base, 
         if (__builtin_expect(is_ev & (uint32_t)(zz_next >= 64), 0)) return InterRun{pos, 0, H263MI_OK, false};             // rle.rs:125-127
         *out = (e & 0xffff0000u) | kZigzagRaster[zz_next & 63u];
         out += is_ev;
-        const uint32_t ev_last = is_ev & (e >> 4);                          // this event ends its block
+        const uint32_t ev_last = is_ev & (e >> kEventLastBit);              // this event ends its block
         const uint32_t coded_b = (coded6 >> (5u - b)) & 1u;
         const uint32_t fin = is_dc ? (coded_b ^ 1u) : ev_last;             // this item ends its block
         fe[1] = events_before + (uint32_t)(out - ev);                        // the block's end (rewritten until its LAST event)
@@ -1365,9 +1373,9 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 const uint32_t n_coded = (uint32_t)__builtin_popcount(coded6);
                 const InterRun ir = sorenson_v1
                     ? inter_macroblock_events<true>(r.data(), r.position(), end64, n_coded, out.events.data() + n_events,
-                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13)
+                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0])
                     : inter_macroblock_events<false>(r.data(), r.position(), end64, n_coded, out.events.data() + n_events,
-                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13);
+                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0]);
                 if (ir.rc != H263MI_OK) return finish(ir.rc);
                 if (ir.done) {
                     r.rollback(ir.pos);
@@ -1382,9 +1390,9 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 uint8_t dcs[8];
                 const InterRun ir = sorenson_v1
                     ? intra_macroblock_events<true>(r.data(), r.position(), end64, coded6, out.events.data() + n_events,
-                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13, dcs)
+                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0], dcs)
                     : intra_macroblock_events<false>(r.data(), r.position(), end64, coded6, out.events.data() + n_events,
-                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13, dcs);
+                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0], dcs);
                 if (ir.rc != H263MI_OK) return finish(ir.rc);
                 if (ir.done) {
                     r.rollback(ir.pos);

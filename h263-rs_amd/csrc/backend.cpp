@@ -1322,6 +1322,12 @@ static uint32_t default_host_threads()
             n = std::min<uint32_t>(n, (uint32_t)std::max(1L, atol(quota) / period));
         fclose(f);
     }
+    // ranks of one job that share the node share its CPUs: the launcher's LOCAL_WORLD_SIZE (torch.distributed.run, mpirun
+    // wrappers) divides the budget, so that 8 ranks do not start 8 x the quota in parser threads
+    if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {
+        const long ranks = atol(lw);
+        if (ranks > 1) n = std::max<uint32_t>(1u, n / (uint32_t)ranks);
+    }
     return n;
 }
 

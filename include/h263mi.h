@@ -360,7 +360,8 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
 /*
  * N x H263State::decode_next_picture(reader) (state.rs:138-141) in one call: data[s] / len[s] hold one coded picture
  * of stream s (what Ruffle hands one reader per FLV video tag).  The serial parse of each stream (state.rs:143-427)
- * runs on `n_threads` host threads (0 = one per hardware thread), one stream per task; the records of all streams
+ * runs on `n_threads` host threads (0 = what this process may use: hardware threads, affinity mask and the container's
+ * CPU quota, whichever is smallest, divided by LOCAL_WORLD_SIZE when a launcher exports it), one stream per task; the records of all streams
  * then cross to the device as events (h263mi_batch_submit_host_events) and ONE launch decodes them: k_recon, or -- on a
  * H263MI_CFG_PIPELINE_POST batch through the _ex form -- k_frame, which also post-processes the previous picture.
  * consumed[s] (may be NULL) receives the bytes used.  decoder_options as for h263mi_state_new.  If any stream fails

@@ -596,6 +596,8 @@ def stub_main(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+        side = dist.new_group(backend="gloo")        # (the side group main() makes for its long host-side waits)
+        dist.barrier(group=side)
     else:
         dist = None
     elapsed = shard.timed_region(dist, lambda: time.sleep(0.01 * args.steps))
@@ -660,7 +662,12 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     # waits that may last seconds (another rank is busy on its HOST) go through a gloo group: a socket wait, where a RCCL
     # barrier spins a host thread per waiting rank
-    host_pg = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
+    host_pg = None
+    if dist is not None and world > 1:
+        try:
+            host_pg = dist.new_group(backend="gloo")
+        except Exception as e:          # (no gloo in this build: the long waits fall back to the RCCL barrier)
+            sys.stderr.write("bench.py: no gloo side group (%s): waiting on RCCL barriers\n" % e)
 
     stream = torch.cuda.current_stream().cuda_stream
     strong = args.total_streams > 0
@@ -940,6 +947,8 @@ def main(argv=None):
             e2e_bad |= extra["single_stream_1080p"]["parity_vs_oracle"] != "ok"
         if host_pg is not None:
             dist.barrier(group=host_pg)          # (rank 0's single-stream leg: the others wait on a socket)
+        elif dist is not None:
+            dist.barrier()
     if dist is not None:
         t = torch.tensor([int(e2e_bad)], dtype=torch.int32, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -985,6 +994,8 @@ def main(argv=None):
     if dist is not None:
         if host_pg is not None:
             dist.barrier(group=host_pg)
+        else:
+            dist.barrier()
         dist.destroy_process_group()
     # a mismatch anywhere -- the main gate or an end-to-end leg, on any rank -- fails the run
     return 1 if (gate_bad or e2e_bad) else 0

@@ -1158,7 +1158,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         for (uint32_t i = first; i < last; i += step) {
             if (!b->ss[i].active) continue;      // sits the call out: its records are never read (STREAM_RECON_SKIP)
             MbRecord *dst = g2.h_mbs + (size_t)i * per;
-            if (sparse_rec) memcpy(g2.h_index + (size_t)i * groups_pp, group_index[i], groups_pp * sizeof(uint32_t));
+            if (sparse_rec) {
+                if (group_index[i]) memcpy(g2.h_index + (size_t)i * groups_pp, group_index[i], groups_pp * sizeof(uint32_t));
+                else memset(g2.h_index + (size_t)i * groups_pp, 0, groups_pp * sizeof(uint32_t));      // (no record at all)
+            }
             for (uint32_t k = 0; k < n_mbs[i] && !from_parser; k++) {   // the same checks as h263mi_submit_picture
                 const MbRecord &m = mbs[i][k];
                 // (a record without coded blocks does not use its coeff_index)
@@ -1802,6 +1805,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
     DeviceGuard g(m->cfg.device_id);
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
     // ---- the serial half of decode_next_picture (state.rs:143-427) per stream, on the host threads
+    static const bool mixed_sparse = !(getenv("H263MI_SPARSE_RECORDS") && getenv("H263MI_SPARSE_RECORDS")[0] == '0');
     std::vector<int> rcs(n, H263MI_OK);
     const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
     StreamDeal deal(n);
@@ -1811,6 +1815,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
             bits::ParsedPicture &pic = m->parsed[i];
             pic.want_dense = false;
             pic.size_fits = &picture_size_fits;
+            pic.sparse_records = mixed_sparse;   // records for the coded macroblocks only (see batch_submit_host)
             pic.mbs_ext = nullptr;               // (the class -- and with it the staging slot -- is known after the header)
             pic.mbs_ext_cap = 0;
             rcs[i] = bits::parse_picture(data[i], len[i], decoder_options, &m->parser_ctx[i], pic);
@@ -1831,10 +1836,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
         const uint32_t w = pic.desc.width, h = pic.desc.height;
         int rc = H263MI_OK;
         if (!w || !h || !layout_fits(w, h)) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;
-        const size_t per = (size_t)((w + 15) / 16) * ((h + 15) / 16);
-        bool any_inter = pic.n_records() < per;                     // missing macroblocks are padded as Inter (state.rs:421-427)
-        const h263mi_mb_record *r = pic.records();
-        for (size_t k = 0, e = pic.n_records(); k < e && !any_inter; k++) any_inter = mb_is_inter(r[k].mb_type);
+        const bool any_inter = pic.any_inter;       // (the parser's: inter types, macroblocks not coded, macroblocks not reached)
         const int c_old = m->cls[i];
         const bool same = c_old >= 0 && m->classes[c_old].w == w && m->classes[c_old].h == h;
         const h263mi_batch::StreamState *st_old = c_old >= 0 ? &m->classes[c_old].b->ss[m->slot[i]] : nullptr;
@@ -1913,7 +1915,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
         if (!b) continue;                        // (a class that was given up)
         const uint32_t slots = b->n;
         std::vector<const h263mi_mb_record *> mbs(slots, nullptr);
-        std::vector<const uint32_t *> first(slots, kNoEvents), events(slots, nullptr);
+        std::vector<const uint32_t *> first(slots, kNoEvents), events(slots, nullptr), gidx(slots, nullptr);
         std::vector<uint32_t> n_mbs(slots, 0), n_blocks(slots, 0), n_events(slots, 0);
         std::vector<uint8_t> types(slots, H263MI_PICTURE_P), was_active(slots, 0);
         std::vector<uint8_t *> out_ptrs(slots, nullptr);
@@ -1932,6 +1934,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
             n_mbs[s] = (uint32_t)pic.n_records();
             first[s] = pic.block_first_event.data();
             events[s] = pic.events.data();
+            gidx[s] = pic.group_index.data();
             n_blocks[s] = (uint32_t)pic.n_coded_blocks;
             n_events[s] = (uint32_t)pic.events.size();
             types[s] = pic.desc.picture_type;
@@ -1944,7 +1947,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
         if (members) {
             const bool deferred = b->pipeline_post && any_out;
             rc = batch_submit_host(b, H263MI_PICTURE_P, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
-                                   n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred);
+                                   n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred, mixed_sparse ? gidx.data() : nullptr);
             if (rc == H263MI_OK) {
                 c.submitted = true;
                 // the pictures are decoded: the streams move to this class, their parser state moves on (state.rs:464-483)

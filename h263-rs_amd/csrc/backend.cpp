@@ -1087,13 +1087,23 @@ int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263
 
 }  // extern "C"
 
+// DIRECT WORDS (round 5, h263mi_batch_decode_next_pictures only): the parser has written every stream's block offsets, events
+// and group index straight into the staging slot -- stream i's block offsets at h_events + i * pitch_blocks, its events at
+// h_events + n * pitch_blocks + i * pitch_events, the offsets counting from i * pitch_events -- so nothing is packed: the
+// used head of every stream's part crosses the link in one 2-D copy per array.  The pitches are the worst case of the
+// call's pictures (bits::event_words_bound), known from their lengths before a bit is parsed.
+struct DirectWords {
+    size_t pitch_blocks, pitch_events;
+};
+
 // one picture per stream from per-stream host arrays; coefficients dense (`coeffs`) or as events (`first_event`,
 // `events`, `n_events`)
 static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *const *mbs,
                              const uint32_t *n_mbs, const int16_t *const *coeffs, const uint32_t *n_coeff_blocks,
                              const uint32_t *const *first_event, const uint32_t *const *events, const uint32_t *n_events,
                              bool from_parser = false, uint32_t pack_threads = 0, const uint8_t *types = nullptr,
-                             bool deferred_post = false, const uint32_t *const *group_index = nullptr)
+                             bool deferred_post = false, const uint32_t *const *group_index = nullptr,
+                             const DirectWords *direct = nullptr)
 {
     // group_index (from the parser only): SPARSE RECORDS -- mbs[i] holds the n_mbs[i] records of stream i's coded macroblocks
     // (written in place at the head of the stream's part of the staging slot) and group_index[i] one word per group of 8
@@ -1103,7 +1113,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     // -- the packing pass and the parser without its non-temporal stores cost more than the plain copy saves; and so was letting
     // the waves read the records out of the pinned slot over the link, no copy at all: +-0.  In the steady state a call IS its
     // parse phase: 0.43-0.53 ms on 16 threads against 0.03 ms of packing and 0.01 ms of enqueueing
-    // (profiles/r05_j_e2e_per_call_packed_records.txt, r05_m_*).)
+    // (profiles/r05_j_e2e_per_call_packed_records.txt, r05_m_*).  The packing went last: `direct`, below.)
     const bool sparse_rec = group_index != nullptr && from_parser;
     // from_parser: the arrays are what bits::parse_picture just wrote (h263mi_batch_decode_next_pictures) -- valid by
     // construction, so the per-record checks a caller's arrays get are skipped; pack_threads: the caller's thread budget
@@ -1115,7 +1125,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     size_t blocks = 0, n_ev = 0;
     for (uint32_t i = 0; i < b->n; i++) {
         if (n_mbs[i] > per || (n_mbs[i] && !mbs[i])) return H263MI_ERR_INVALID_ARGUMENT;
-        if (n_coeff_blocks[i]) {
+        if (n_coeff_blocks[i] && !direct) {
             if (!sparse && !coeffs[i]) return H263MI_ERR_INVALID_ARGUMENT;
             if (sparse && (!first_event[i] || first_event[i][0] != 0 || first_event[i][n_coeff_blocks[i]] != n_events[i] ||
                            (n_events[i] && !events[i])))
@@ -1130,8 +1140,11 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     DeviceGuard g(b->device);
     if (!g.ok) return H263MI_ERR_NO_DEVICE;
     h263mi_batch::HostStaging &g2 = b->host_stg[b->host_slot & 1];
-    const size_t event_words = sparse ? blocks + 1 + n_ev : 0;
-    RC_TRY(b->ensure_host_staging(g2, blocks ? blocks : 1, event_words));
+    if (direct && !(from_parser && sparse && group_index)) return H263MI_ERR_INVALID_ARGUMENT;
+    // (direct: the slot was sized before the parser wrote into it, batch_decode_next_pictures)
+    const size_t event_words = direct ? (size_t)b->n * (direct->pitch_blocks + direct->pitch_events) : sparse ? blocks + 1 + n_ev : 0;
+    if (direct && (b->head_words() + event_words > g2.cap_words || event_words > kMaxEventWords)) return H263MI_ERR_INVALID_ARGUMENT;
+    if (!direct) RC_TRY(b->ensure_host_staging(g2, blocks ? blocks : 1, event_words));
     const auto t_wait0 = std::chrono::steady_clock::now();
     HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
     const auto t_pack0 = std::chrono::steady_clock::now();
@@ -1141,11 +1154,15 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     pad.mb_type = H263MI_MB_INTER;
     pad.quant = 1;
     std::vector<uint32_t> ev_base(b->n + 1, 0);
-    size_t at = 0, rec_at = 0;
+    size_t at = 0, rec_at = 0, most_blocks = 0, most_events = 0;
     const size_t groups_pp = (size_t)recon_tiles_x(b->L) * b->L.mbh;
     for (uint32_t i = 0; i < b->n; i++) {        // coeff_index of stream i counts from its own first block
-        g2.h_base[i] = at;
+        g2.h_base[i] = direct ? (uint64_t)i * direct->pitch_blocks : at;
         at += n_coeff_blocks[i];
+        if (direct && b->ss[i].active) {
+            most_blocks = std::max<size_t>(most_blocks, n_coeff_blocks[i]);
+            most_events = std::max<size_t>(most_events, n_events[i]);
+        }
         ev_base[i + 1] = ev_base[i] + (sparse ? n_events[i] : 0);
         g2.h_base[b->n + i] = (uint64_t)i * per; // (sparse records: stream i's first record)
         if (sparse_rec && b->ss[i].active && n_mbs[i] > rec_at) rec_at = n_mbs[i];
@@ -1201,7 +1218,9 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
     const size_t bytes = (sparse_rec ? records_sent * b->n : (size_t)b->n * per) * sizeof(MbRecord) + (sparse ? event_words * 4 : blocks * 128);
     const uint32_t n_thr = bytes < (4u << 20) ? 1u
                          : std::min<uint32_t>({pack_threads ? pack_threads : 8u, b->n, std::max(1u, std::thread::hardware_concurrency())});
-    if (n_thr <= 1) {
+    if (direct) {
+        // nothing to pack: records, index, block offsets and events are where the copies read them
+    } else if (n_thr <= 1) {
         pack(0, b->n, 1);
     } else {
         // (thread t packs the streams t, t + T, ...: the ones it has just parsed, see StreamDeal)
@@ -1231,6 +1250,21 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
                                    hipMemcpyHostToDevice, cs));
             i = j;
         }
+        if (direct) {
+            // the bases and the record index in one copy, the used heads of the streams' block offsets and events in a 2-D
+            // copy each
+            HIP_TRY(hipMemcpyAsync(g2.d_words, g2.h_words, b->head_words() * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+            if (blocks) {
+                uint32_t *const h_ev0 = g2.h_events + (size_t)b->n * direct->pitch_blocks;
+                uint32_t *const d_ev0 = g2.d_events + (size_t)b->n * direct->pitch_blocks;
+                HIP_TRY(hipMemcpy2DAsync(g2.d_events, direct->pitch_blocks * sizeof(uint32_t), g2.h_events, direct->pitch_blocks * sizeof(uint32_t),
+                                         (most_blocks + 1) * sizeof(uint32_t), b->n, hipMemcpyHostToDevice, cs));
+                if (most_events)
+                    HIP_TRY(hipMemcpy2DAsync(d_ev0, direct->pitch_events * sizeof(uint32_t), h_ev0, direct->pitch_events * sizeof(uint32_t),
+                                             most_events * sizeof(uint32_t), b->n, hipMemcpyHostToDevice, cs));
+            }
+            return H263MI_OK;
+        }
         // the bases, the record index and the events: one copy (HostStaging::h_words)
         if (sparse && blocks) h_first[blocks] = (uint32_t)n_ev;
         HIP_TRY(hipMemcpyAsync(g2.d_words, g2.h_words, (b->head_words() + (sparse && blocks ? event_words : 0)) * sizeof(uint32_t),
@@ -1253,10 +1287,10 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         // the reconstruction waves read the events themselves (recon_kernel.inl: coeff_row_from_events); round 2 had a
         // kernel of its own (k_expand) rebuild dense blocks in HBM first
         b->cur_first_event = g2.d_events;
-        b->cur_events = g2.d_events + blocks + 1;
-        b->cur_n_events = (uint32_t)n_ev;
+        b->cur_events = direct ? g2.d_events + (size_t)b->n * direct->pitch_blocks : g2.d_events + blocks + 1;
+        b->cur_n_events = direct ? (uint32_t)((size_t)b->n * direct->pitch_events) : (uint32_t)n_ev;
     }
-    b->coeff_pool_blocks = blocks;
+    b->coeff_pool_blocks = direct ? (uint64_t)b->n * direct->pitch_blocks : blocks;
     b->coeff_checked = true;
     if (sparse_rec) {
         b->cur_group_index = g2.d_index;
@@ -1373,6 +1407,25 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     const size_t per = (size_t)b->L.mbw * b->L.mbh;
     // H263MI_SPARSE_RECORDS=0: dense record arrays over the link, as rounds 2-4 sent them (A/B switch)
     static const bool sparse_rec = !(getenv("H263MI_SPARSE_RECORDS") && getenv("H263MI_SPARSE_RECORDS")[0] == '0');
+    // DIRECT WORDS (see DirectWords): every stream's events, block offsets and group index are parsed straight into the
+    // staging slot, at pitches that hold the worst case of this call's pictures -- as long as that worst case is a sensible
+    // amount of pinned memory (a 1080p key frame of 100 KB: 1 MB per stream; the 2.3 MB test key frames take the packed form).
+    // H263MI_DIRECT_WORDS=0: the packed form always (A/B switch).
+    static const bool direct_allowed = !(getenv("H263MI_DIRECT_WORDS") && getenv("H263MI_DIRECT_WORDS")[0] == '0');
+    constexpr size_t kDirectEventBytesMax = (size_t)256 << 20;
+    DirectWords dw{0, 0};
+    bool direct = sparse_rec && direct_allowed;
+    if (direct) {
+        size_t longest = 0;
+        for (uint32_t i = 0; i < n; i++)
+            if (data[i] && b->ss[i].active) longest = std::max(longest, len[i]);
+        dw.pitch_blocks = (bits::block_offset_words_bound(per) + 15) & ~(size_t)15;
+        dw.pitch_events = (bits::event_words_bound(longest, per) + 15) & ~(size_t)15;
+        direct = (size_t)n * dw.pitch_events * sizeof(uint32_t) <= kDirectEventBytesMax &&
+                 (size_t)n * (dw.pitch_events + dw.pitch_blocks) <= kMaxEventWords;
+        if (direct) RC_TRY(b->ensure_host_staging(g2, 1, (size_t)n * (dw.pitch_blocks + dw.pitch_events)));
+    }
+    const size_t groups_pp = (size_t)recon_tiles_x(b->L) * b->L.mbh;
     // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
     std::vector<int> rcs(n, H263MI_OK);
     const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
@@ -1386,8 +1439,17 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
             pic.sparse_records = sparse_rec;                     // records for the coded macroblocks only (round 5)
             pic.mbs_ext = g2.h_mbs + (size_t)i * per;
             pic.mbs_ext_cap = per;
+            pic.events_ext = direct ? g2.h_events + (size_t)n * dw.pitch_blocks + (size_t)i * dw.pitch_events : nullptr;
+            pic.events_ext_cap = direct ? dw.pitch_events : 0;
+            pic.first_event_ext = direct ? g2.h_events + (size_t)i * dw.pitch_blocks : nullptr;
+            pic.first_event_ext_cap = direct ? dw.pitch_blocks : 0;
+            pic.group_index_ext = direct ? g2.h_index + (size_t)i * groups_pp : nullptr;
+            pic.group_index_ext_cap = direct ? groups_pp : 0;
+            pic.event_base = direct ? (uint32_t)((size_t)i * dw.pitch_events) : 0u;
             int rc = bits::parse_picture(data[i], len[i], decoder_options, &b->parser_ctx[i], pic);
             if (rc == H263MI_OK && (pic.desc.width != b->L.width || pic.desc.height != b->L.height)) rc = H263MI_ERR_PICTURE_FORMAT_INVALID;
+            // (a picture of the batch's size fits the pitches by construction: anything else is a fault of this library)
+            if (rc == H263MI_OK && direct && !pic.words_ext_used) rc = H263MI_ERR_INTERNAL_DECODER_ERROR;
             // gather.rs:149: an inter macroblock without a reference picture is Error::UncodedIFrameBlocks -- found here,
             // before anything is queued, so that the stream (parser state included) stays as it was (macroblocks the picture
             // does not code are padded as Inter, state.rs:421-427: the parser's any_inter covers them)
@@ -1433,11 +1495,11 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
         if (!takes_part[i]) continue;
         mbs[i] = pic.records();
         n_mbs[i] = (uint32_t)pic.n_records();
-        gidx[i] = pic.group_index.data();
-        first[i] = pic.block_first_event.data();
-        events[i] = pic.events.data();
+        gidx[i] = pic.group_index_words();
+        first[i] = pic.first_event_words();
+        events[i] = pic.event_words();
         n_blocks[i] = (uint32_t)pic.n_coded_blocks;
-        n_events[i] = (uint32_t)pic.events.size();
+        n_events[i] = (uint32_t)pic.n_event_words();
     }
     // the streams that take part in THIS call (restored below: h263mi_batch_set_active is the caller's)
     std::vector<uint8_t> was_active(n);
@@ -1447,7 +1509,8 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     }
     const bool deferred = b->pipeline_post && (d_rgba || d_deblocked);
     int rc = batch_submit_host(b, H263MI_PICTURE_P, mbs.data(), n_mbs.data(), nullptr, n_blocks.data(), first.data(), events.data(),
-                               n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred, sparse_rec ? gidx.data() : nullptr);
+                               n_events.data(), /*from_parser=*/true, n_thr, types.data(), deferred, sparse_rec ? gidx.data() : nullptr,
+                               direct ? &dw : nullptr);
     int render_rc = H263MI_OK;
     if (rc == H263MI_OK) {
         // the pictures are decoded: what the streams remember of their headers moves on with them, whatever happens to the

@@ -1026,6 +1026,8 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     out.mbs.clear();
     out.n_mbs_ext = 0;
     out.mbs_ext_used = false;
+    out.n_events_ext = 0;
+    out.words_ext_used = false;
     out.coeffs.clear();
     out.block_first_event.clear();
     // (out.events keeps its size as the room to write into -- its elements are plain words -- and is cut to the events
@@ -1090,18 +1092,26 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
     // sparse records (ParsedPicture::sparse_records): no record for a macroblock that is not coded, a word per group of 8
     const bool sparse_rec = out.sparse_records;
     const size_t groups_per_line = (mb_per_line + 7) / 8;
+    // the word arrays -- events, block offsets, group index -- go to the caller's memory when all of it can hold this picture's
+    // worst case (ParsedPicture::events_ext): nothing below ever checks for room there
+    const bool wext = !want_dense && out.events_ext && out.first_event_ext && out.events_ext_cap >= event_words_bound(len, total) &&
+                      out.first_event_ext_cap >= block_offset_words_bound(total) &&
+                      (!sparse_rec || (out.group_index_ext && out.group_index_ext_cap >= groups_per_line * mb_height));
+    out.words_ext_used = wext;
+    const uint32_t event_base = wext ? out.event_base : 0u;
     out.group_index.clear();
-    if (sparse_rec) out.group_index.assign(groups_per_line * mb_height, 0u);
-    uint32_t *const group_index = out.group_index.data();
+    if (sparse_rec && wext) memset(out.group_index_ext, 0, groups_per_line * mb_height * sizeof(uint32_t));
+    else if (sparse_rec) out.group_index.assign(groups_per_line * mb_height, 0u);
+    uint32_t *const group_index = wext ? out.group_index_ext : out.group_index.data();
     size_t n_rec = 0;                                // records written (== n_mbs unless sparse)
     bool any_inter = false;
     // (no zero-fill of the record array: a record is assembled in registers and stored whole, 32 bytes, when its macroblock
     // is done -- round 3 cleared 261 KB per 1080p picture first and then wrote most of it again)
     if (!ext) out.mbs.resize(total);
     h263mi_mb_record *const recs = ext ? out.mbs_ext : out.mbs.data();
-    out.block_first_event.resize((total + 1) * 6 + 1);
-    uint32_t *const first_event = out.block_first_event.data();
-    first_event[0] = 0;
+    if (!wext) out.block_first_event.resize(block_offset_words_bound(total));
+    uint32_t *const first_event = wext ? out.first_event_ext : out.block_first_event.data();
+    first_event[0] = event_base;
     size_t n_mbs = 0, n_events = 0, n_blocks = 0;
     // A record is written once and never read again by this thread -- in the product it lies in pinned staging memory that
     // only the copy engine reads: non-temporal stores (no read-for-ownership of the line, no place taken in the caches the
@@ -1129,8 +1139,14 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
         out.any_inter = any_inter || n_mbs < total;      // (macroblocks the bitstream does not reach are padded as Inter, state.rs:421-427)
         if (ext) out.n_mbs_ext = sparse_rec ? n_rec : (n_mbs < total ? n_mbs : total);
         else out.mbs.resize(sparse_rec ? n_rec : n_mbs);
-        out.block_first_event.resize(n_blocks + 1);
-        out.events.resize(n_events);
+        if (wext) {
+            out.block_first_event.clear();
+            out.events.clear();
+            out.n_events_ext = n_events;
+        } else {
+            out.block_first_event.resize(n_blocks + 1);
+            out.events.resize(n_events);
+        }
         out.n_coded_blocks = n_blocks;
         return code;
     };
@@ -1355,7 +1371,8 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
             rec.quant = (uint8_t)in_force_quantizer;
             rec.coeff_index = (uint32_t)n_blocks;
             // room for the events of this macroblock (6 blocks x 64 at most)
-            if (out.events.size() < n_events + 6 * 64) out.events.resize((n_events + 6 * 64) * 2);
+            if (!wext && out.events.size() < n_events + 6 * 64) out.events.resize((n_events + 6 * 64) * 2);
+            uint32_t *const events_now = wext ? out.events_ext : out.events.data();
             const uint32_t coded6 = ((uint32_t)luma << 2) | ((uint32_t)cb << 1) | (uint32_t)cr;   // bit 5 - b: block b
             // state.rs:287-381: the six blocks in order; an inter block without TCOEFs has no bits at all (block.rs:
             // 684-687), so an inter macroblock only visits its coded blocks (no branch per absent block)
@@ -1372,10 +1389,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 // every coded block of an inter macroblock in one loop (inter_macroblock_events)
                 const uint32_t n_coded = (uint32_t)__builtin_popcount(coded6);
                 const InterRun ir = sorenson_v1
-                    ? inter_macroblock_events<true>(r.data(), r.position(), end64, n_coded, out.events.data() + n_events,
-                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0])
-                    : inter_macroblock_events<false>(r.data(), r.position(), end64, n_coded, out.events.data() + n_events,
-                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0]);
+                    ? inter_macroblock_events<true>(r.data(), r.position(), end64, n_coded, events_now + n_events,
+                                                    first_event + n_blocks, event_base + (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0])
+                    : inter_macroblock_events<false>(r.data(), r.position(), end64, n_coded, events_now + n_events,
+                                                     first_event + n_blocks, event_base + (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0]);
                 if (ir.rc != H263MI_OK) return finish(ir.rc);
                 if (ir.done) {
                     r.rollback(ir.pos);
@@ -1389,10 +1406,10 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 // the six blocks of an intra macroblock as one list of items (intra_macroblock_events)
                 uint8_t dcs[8];
                 const InterRun ir = sorenson_v1
-                    ? intra_macroblock_events<true>(r.data(), r.position(), end64, coded6, out.events.data() + n_events,
-                                                    first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0], dcs)
-                    : intra_macroblock_events<false>(r.data(), r.position(), end64, coded6, out.events.data() + n_events,
-                                                     first_event + n_blocks, (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0], dcs);
+                    ? intra_macroblock_events<true>(r.data(), r.position(), end64, coded6, events_now + n_events,
+                                                    first_event + n_blocks, event_base + (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0], dcs)
+                    : intra_macroblock_events<false>(r.data(), r.position(), end64, coded6, events_now + n_events,
+                                                     first_event + n_blocks, event_base + (uint32_t)n_events, ht.tcoef13[sorenson_v1 ? 1 : 0], dcs);
                 if (ir.rc != H263MI_OK) return finish(ir.rc);
                 if (ir.done) {
                     r.rollback(ir.pos);
@@ -1415,7 +1432,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                     out.coeffs.resize(base + 64, 0);
                     dense = out.coeffs.data() + base;
                 }
-                uint32_t *const ev = out.events.data() + n_events;     // a block places 64 events at most
+                uint32_t *const ev = events_now + n_events;            // a block places 64 events at most
                 size_t zz = intra ? 1 : 0, n_ev = 0;
                 bool overrun = false;
                 uint8_t dc = 0;
@@ -1453,7 +1470,7 @@ int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, con
                 rec.cbp |= (uint8_t)(1u << b);
                 if (overrun) rec.kill |= (uint8_t)(1u << b);
                 n_events += n_ev;
-                first_event[++n_blocks] = (uint32_t)n_events;
+                first_event[++n_blocks] = event_base + (uint32_t)n_events;
             }
         }
         if (n_mbs >= total) {

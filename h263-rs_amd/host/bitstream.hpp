@@ -243,6 +243,20 @@ struct ParsedPicture {
     // (Macroblocks the bitstream does not reach have none either: they are padded as not coded, state.rs:421-427.)
     bool sparse_records = false;
     WordBuffer group_index;
+    // Optional destinations of the WORD arrays (set before parsing; e.g. a stream's part of a pinned staging slot): when all
+    // of them are given and large enough for the worst case of this picture -- events: event_words_bound(len, macroblocks);
+    // block offsets: block_offset_words_bound(macroblocks); index: one word per group -- the events, the block offsets and the
+    // group index are written there and the vectors above stay empty (words_ext_used; n_events_ext says how many events).
+    // The block offsets then count from `event_base` (block k = [first[k], first[k+1]) - event_base of events_ext): a caller
+    // that lays the streams' parts out one behind the other needs no second pass over any of it.
+    uint32_t *events_ext = nullptr, *first_event_ext = nullptr, *group_index_ext = nullptr;
+    size_t events_ext_cap = 0, first_event_ext_cap = 0, group_index_ext_cap = 0, n_events_ext = 0;
+    uint32_t event_base = 0;
+    bool words_ext_used = false;
+    const uint32_t *event_words() const { return words_ext_used ? events_ext : events.data(); }
+    size_t n_event_words() const { return words_ext_used ? n_events_ext : events.size(); }
+    const uint32_t *first_event_words() const { return words_ext_used ? first_event_ext : block_first_event.data(); }
+    const uint32_t *group_index_words() const { return words_ext_used ? group_index_ext : group_index.data(); }
     size_t n_macroblocks = 0;              // macroblocks the bitstream held (records + the ones without one)
     // some macroblock takes a prediction (inter type, not coded, or not reached by the bitstream): the picture needs a
     // reference picture (gather.rs:149).  Set by the parser in every mode.
@@ -261,6 +275,15 @@ struct ParsedPicture {
     WordBuffer scratch;                    // parser-internal (the vectors of the macroblocks decoded so far)
     ParserContext next;                    // the context once this picture has been decoded successfully
 };
+// The most event words a picture of `len` bytes and `macroblocks` macroblocks can make the parser write: an event is a
+// code word of two bits at least and a sign (block.rs:689-724), a block places 64 at most, and the parser wants room for one
+// whole macroblock (6 x 64) in front of its cursor.
+inline size_t event_words_bound(size_t len, size_t macroblocks)
+{
+    const size_t by_bits = len * 8 / 3 + 1, by_blocks = macroblocks * 6 * 64;
+    return (by_bits < by_blocks ? by_bits : by_blocks) + 6 * 64 + 8;
+}
+inline size_t block_offset_words_bound(size_t macroblocks) { return (macroblocks + 1) * 6 + 1; }
 // Returns H263MI_OK or the error the reference's decode_next_picture would return before touching any
 // pixel.  `ctx`: the last decoded picture (null = none), needed by standard H.263 headers that carry no format.
 int parse_picture(const uint8_t *data, size_t len, uint32_t decoder_options, const ParserContext *ctx, ParsedPicture &out);

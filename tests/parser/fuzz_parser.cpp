@@ -320,6 +320,47 @@ struct Worker {
         // reference policy (state.rs:387-408): macroblock-header errors resynchronise in standard mode and only there
         if (!(options & 1u) && (ra == H263MI_ERR_INVALID_MACROBLOCK_HEADER || ra == H263MI_ERR_INVALID_MACROBLOCK_CODED_BITS))
             report("a standard-mode parse returned a macroblock-header error instead of resynchronising", d, options, index);
+        {
+            // the caller's WORD arrays (ParsedPicture::events_ext: what the batch entry's staging slot is): exactly the bounds the
+            // parser asks for, no slack -- ASan guards the ends -- for EVERY input, parsed or not (what is written before an
+            // error is found must stay inside too); then one word less, which must send everything back into the vectors
+            const size_t mbw = (fresh_fast.desc.width + 15) / 16, mbh = (fresh_fast.desc.height + 15) / 16, total = mbw * mbh;
+            const size_t groups = ((mbw + 7) / 8) * mbh;
+            for (int shrink = 0; shrink < 2 && total; shrink++) {
+                const size_t cap_e = h263mi::bits::event_words_bound(len, total) - (size_t)shrink;
+                const size_t cap_f = h263mi::bits::block_offset_words_bound(total), cap_g = groups;
+                uint32_t *ev = (uint32_t *)malloc(cap_e * 4), *fe = (uint32_t *)malloc(cap_f * 4), *gi = (uint32_t *)malloc((cap_g ? cap_g : 1) * 4);
+                h263mi_mb_record *slot = (h263mi_mb_record *)malloc(total * sizeof(h263mi_mb_record));
+                ParsedPicture w;
+                w.want_dense = false;
+                w.size_fits = &fits_small;
+                w.sparse_records = true;
+                w.mbs_ext = slot; w.mbs_ext_cap = total;
+                w.events_ext = ev; w.events_ext_cap = cap_e;
+                w.first_event_ext = fe; w.first_event_ext_cap = cap_f;
+                w.group_index_ext = gi; w.group_index_ext_cap = cap_g;
+                w.event_base = 0x01000000u + (uint32_t)(index & 0xffff);
+                if (parse_picture(data, len, options, nullptr, w) != ra) report("the caller's word arrays change the return code", d, options, index);
+                if (w.words_ext_used != (shrink == 0)) report("the caller's word arrays: wrong destination chosen", d, options, index);
+                if (ra == H263MI_OK) {
+                    ParsedPicture sp;
+                    sp.want_dense = false;
+                    sp.size_fits = &fits_small;
+                    sp.sparse_records = true;
+                    (void)parse_picture(data, len, options, nullptr, sp);
+                    const uint32_t base = shrink ? 0u : w.event_base;
+                    bool same = w.n_coded_blocks == sp.n_coded_blocks && w.n_event_words() == sp.events.size() && w.n_records() == sp.n_records() &&
+                                w.bits_consumed == sp.bits_consumed && w.any_inter == sp.any_inter && w.n_macroblocks == sp.n_macroblocks;
+                    for (size_t k = 0; same && k <= sp.n_coded_blocks; k++) same = w.first_event_words()[k] == sp.block_first_event[k] + base;
+                    same = same && (sp.events.empty() || !memcmp(w.event_words(), sp.events.data(), sp.events.size() * 4));
+                    same = same && (!groups || !memcmp(w.group_index_words(), sp.group_index.data(), groups * 4));
+                    same = same && (!sp.n_records() || !memcmp(w.records(), sp.records(), sp.n_records() * sizeof(h263mi_mb_record)));
+                    if (!same) report("the caller's word arrays hold something else than the vectors", d, options, index);
+                    if (!shrink && (!w.events.empty() || !w.block_first_event.empty() || !w.group_index.empty())) report("words in both destinations", d, options, index);
+                }
+                free(ev); free(fe); free(gi); free(slot);
+            }
+        }
         if (ra == H263MI_OK) {
             st.parsed_ok++;
             int why = 0;

@@ -381,24 +381,43 @@ for f in range(5):
         assert rc == 0
     used, rcs = b.decode_next_pictures_ex(datas, n_threads=3, strength=5, d_rgba=d_rgba.ptr)
     assert not any(rcs), rcs
+# a call in which one stream has no picture and another one's data ends inside the picture: both keep what they had, the others
+# go on (the staging slot holds whatever the failed parse left in its part)
+datas = []
+for s in range(n):
+    mbs, co = recgen.realistic_inter_picture(w, h, 900 + s, p_skip=0.5, p_coded=0.3, quant=q)
+    mbs = make_codable(mbs, q, s + 9, 1)
+    data = enc.encode_picture(w, h, 1, q, mbs, co, temporal_reference=5)
+    if s == 2:
+        data = data[:len(data) // 2]
+    elif s == 4:
+        data = None
+    else:
+        rc, refs[s] = orc.decode_picture(w, h, mbs, co, refs[s])
+        assert rc == 0
+    datas.append(data)
+used, rcs = b.decode_next_pictures_ex(datas, n_threads=2, strength=5, d_rgba=d_rgba.ptr)
+assert rcs[2] != 0 and not any(rc for s, rc in enumerate(rcs) if s != 2), rcs
 b.sync()
 for s in range(n):
     got = b.copy_yuv(s)
     assert all((g == e).all() for g, e in zip(got, refs[s])), s
     cw = (w + 1) // 2
     filt = tuple(orc.deblock(p, pw, 5) for p, pw in zip(refs[s], (w, cw, cw)))
-    assert (d_rgba.download(w * h * 4, s * w * h * 4) == orc.yuv420_to_rgba(*filt, w)).all(), s
+    assert (d_rgba.download(w * h * 4, s * w * h * 4) == orc.yuv420_to_rgba(*filt, w)).all(), s      # (2 and 4: their last picture's)
 b.close()
 print("sparse-probe-ok")
 '''
 
 
-@pytest.mark.parametrize("sparse", ["1", "0"], ids=["sparse_records", "dense_records"])
-def test_sparse_and_dense_record_transport_decode_alike(sparse):
+# (H263MI_DIRECT_WORDS, round 5: the parser writes events, block offsets and group index straight into the staging slot, at
+# pitches that hold the worst case of the call's pictures -- the default -- or into its own vectors, packed afterwards)
+@pytest.mark.parametrize("sparse,direct", [("1", "1"), ("1", "0"), ("0", "1")], ids=["sparse_records_direct_words", "sparse_records_packed_words", "dense_records"])
+def test_sparse_and_dense_record_transport_decode_alike(sparse, direct):
     import subprocess
     import sys
     root = os.path.dirname(HERE)
     code = _SPARSE_PROBE % (root, os.path.join(root, "h263-rs_amd"), HERE)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, H263MI_SPARSE_RECORDS=sparse), capture_output=True,
-                         text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, H263MI_SPARSE_RECORDS=sparse, H263MI_DIRECT_WORDS=direct),
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sparse-probe-ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

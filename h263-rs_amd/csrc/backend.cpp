@@ -1412,7 +1412,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     // amount of pinned memory (a 1080p key frame of 100 KB: 1 MB per stream; the 2.3 MB test key frames take the packed form).
     // H263MI_DIRECT_WORDS=0: the packed form always (A/B switch).
     static const bool direct_allowed = !(getenv("H263MI_DIRECT_WORDS") && getenv("H263MI_DIRECT_WORDS")[0] == '0');
-    constexpr size_t kDirectEventBytesMax = (size_t)256 << 20;
+    constexpr size_t kDirectEventBytesMax = (size_t)128 << 20;
     DirectWords dw{0, 0};
     bool direct = sparse_rec && direct_allowed;
     if (direct) {

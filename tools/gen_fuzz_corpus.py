@@ -49,6 +49,16 @@ def seeds():
     out.append((SORENSON, enc.encode_picture(176, 144, 1, 9, make_codable(mbs, 9, 2, 1), co)))
     mbs, co = recgen.inter_picture(176, 144, seed=52, mv_range=32, p_4v=0.2, p_intra=0.05, p_coded=0.2, quant=10, max_level=40)
     out.append((SORENSON, enc.encode_picture(176, 144, 1, 10, make_codable(mbs, 10, 3, 1), co)))
+    # the densest stream there is: every block of every macroblock 64 coefficients of +-1 (run 0, level 1: the 3-bit code
+    # words) -- 3.03 bits per event, next to the bound the caller's event arrays are sized by (bits::event_words_bound)
+    for ptype in (1, 0):
+        rng = np.random.default_rng(70 + ptype)
+        mbs, _ = (recgen.inter_picture(48, 32, seed=71, mv_range=4, p_4v=0.0, p_intra=0.0, p_coded=1.0, quant=4, max_level=1)
+                  if ptype else recgen.intra_picture(48, 32, seed=72, max_level=1, quant=4))
+        mbs["cbp"] = 0x3f
+        mbs["coeff_index"] = np.arange(len(mbs), dtype=np.uint32) * 6
+        co = rng.choice(np.array([-1, 1], np.int16), (len(mbs) * 6, 64))
+        out.append((SORENSON, enc.encode_picture(48, 32, 0 if ptype == 0 else 1, 4, make_codable(mbs, 4, 7, ptype), co)))
     # ITU-T H.263: Annex D vectors (OPPTYPE UMV, both UUI forms)
     for uui, rng_ in (("01", 32), ("1", 64)):
         mbs, co = recgen.inter_picture(176, 144, seed=21, mv_range=rng_, p_4v=0.3, p_coded=0.2, quant=8, max_level=30)

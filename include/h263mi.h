@@ -369,8 +369,10 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  * have the batch's width and height.  The host parser is the bit-at-a-time reader of the reference (reader.rs:94-134,
  * 272-290) redesigned around a 64-bit window and table lookups (h263-rs_amd/host/bitstream.cpp).
  * The host threads belong to the batch (created at the first call, parked between calls); the parser writes a stream's
- * records straight into the pinned staging memory the copy to the device reads.  A batch is driven from one thread at a
- * time.  With H263MI_TRACE_E2E set in the environment the batch prints, when it is destroyed, where the host time of
+ * records, block offsets and events straight into the pinned staging memory the copies to the device read (per-stream parts
+ * sized for the worst case of the call's pictures -- 8 * len[s] / 3 events: hand in ONE coded picture per stream, not the
+ * rest of the file, or the call falls back to packing the arrays in a second pass; two slots, about 2 x 120 MB of pinned
+ * memory for 64 streams of 1080p).  A batch is driven from one thread at a time.  With H263MI_TRACE_E2E set in the environment the batch prints, when it is destroyed, where the host time of
  * these calls went (parser threads / waiting for a staging slot / packing / enqueueing).
  * Every stream decodes in this form: data[s] == NULL is accepted only with len[s] == 0 and is an EMPTY reader (the stream
  * gets the parser's end-of-stream error and, all or nothing, the call fails with it); "no picture for this stream" exists

@@ -1,5 +1,7 @@
 """Per-call wall time of the end-to-end path over one GOP (64 realistic 1080p streams, 16 parser threads): which calls are
-slow -- the key frame, the first P pictures behind it, all of them?  usage (GPU box): python tools/probes/e2e_per_call.py [threads]"""
+slow -- the key frame, the first P pictures behind it, all of them?  usage (GPU box): python tools/probes/e2e_per_call.py [threads]
+E2E_GOPS=22 in the environment: that many GOPs, and the median / best GOP behind the first two at the end (A/B runs of two builds or
+two switches -- H263MI_DIRECT_WORDS=0, H263MI_SPARSE_RECORDS=0 -- alternate this on one lease: profiles/r05_r_ab_direct_words.txt)."""
 import os, sys, time
 import torch
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")

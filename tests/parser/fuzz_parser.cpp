@@ -177,6 +177,7 @@ bool same_pictures(const ParsedPicture &a, const ParsedPicture &b, int &why)
     if (memcmp(&a.desc, &b.desc, sizeof a.desc)) { why = 3; return false; }
     if (a.n_records() != b.n_records() ||
         (a.n_records() && memcmp(a.records(), b.records(), a.n_records() * sizeof(h263mi_mb_record)))) { why = 4; return false; }
+    if (a.any_inter != b.any_inter || a.n_macroblocks != b.n_macroblocks) { why = 5; return false; }
     if (a.events != b.events) { why = 6; return false; }
     if (a.block_first_event != b.block_first_event || a.n_coded_blocks != b.n_coded_blocks) { why = 7; return false; }
     if (a.next.have_last != b.next.have_last || a.next.last_format != b.next.last_format ||

@@ -469,8 +469,9 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
                    % (n, len(order), len(order) - 1, n_distinct, n_frames - 1,
                       "pictures shaped like real content" if realistic else "the bench workload's records (every macroblock coded)",
                       cores, STRENGTH, t_enc),
-           "limit": "host parser: %d threads is the container's CPU quota; the device-resident rate of the same kernels "
-                    "is the headline value" % cores}
+           "limit": "host parser: the container's CPU-time quota (cpu_quota_per_rank CPUs; %d threads that park when they are "
+                    "out of work share it, include/h263mi.h: h263mi_default_parser_threads); the device-resident rate of the "
+                    "same kernels is the headline value" % cores}
     if realistic:
         out["uncoded_macroblock_share"] = round(sum(uncoded) / max(len(uncoded), 1), 3)
     return out
@@ -926,12 +927,15 @@ def main(argv=None):
     e2e_bad = 0
     if not args.no_extra and not args.no_e2e:
         # every rank runs its own 64 streams end to end, on ITS share of the container's CPUs, all at the same time
-        threads = shard.parser_threads_for_rank(physical_cores()[0], world)
+        # ... as many parser threads as the LIBRARY chooses for that share (h263mi_default_parser_threads: under a CPU-time
+        # quota more threads than the quota has CPUs, parked the moment they run out of work -- include/h263mi.h)
+        threads, quota_per_rank = h263mi.default_parser_threads(n)
         if dist is not None:
             dist.barrier()
         for key, realistic in (("e2e_bitstream", False), ("e2e_bitstream_realistic", True)):
             e = e2e_bitstream(h263mi, n, local_rank, stream, d_rgba, parser_threads=threads, realistic=realistic)
             rate, units, seconds = shard.aggregate_rate(dist, e.pop("_pictures"), e.pop("_seconds"))
+            e["cpu_quota_per_rank"] = quota_per_rank or None
             if world > 1:
                 e["all_ranks"] = {"pictures_per_s": round(rate, 1), "realtime_1080p30_streams": round(rate / 30.0, 1),
                                   "pictures": units, "seconds_slowest_rank": round(seconds, 4), "ranks": world,

@@ -88,8 +88,10 @@ struct DeviceGuard {
 // is driven from one thread at a time).
 // A server calls the batch entries back to back, a millisecond apart: waking 15 parked threads through a condition
 // variable cost 50-100 us of every call (twice: parser tasks, then packing).  A worker therefore SPINS on the generation
-// counter for a short while after it has finished a task (kSpinUs) and only then parks; the caller spins likewise while
+// counter for a short while after it has finished a task (spin_us) and only then parks; the caller spins likewise while
 // it waits for the last worker.  An idle batch costs nothing: everybody is parked.
+// Under a CPU-TIME quota (a container's cpu.max) spinning is paid for like parsing: see HostThreadPlan, which then runs more
+// threads than the quota has CPUs and has them park at once.
 class WorkerPool {
 public:
     explicit WorkerPool(unsigned workers)
@@ -108,10 +110,12 @@ public:
         for (std::thread &t : threads_) t.join();
     }
     unsigned size() const { return (unsigned)threads_.size() + 1; }       // the caller counts
-    void run(unsigned k, const std::function<void(unsigned)> &fn)
+    // spin_us: how long a worker that has finished spins for the next task before it parks (see loop())
+    void run(unsigned k, const std::function<void(unsigned)> &fn, long spin_us = kSpinUsDefault)
     {
         if (k > size()) k = size();
         if (k <= 1) { fn(0); return; }
+        spin_us_.store(spin_us, std::memory_order_relaxed);
         fn_ = &fn;
         pending_.store(k - 1, std::memory_order_relaxed);
         {
@@ -160,7 +164,10 @@ private:
         if ((unsigned)CPU_COUNT(&want) < 2 * (unsigned)threads_.size() + 2 || CPU_COUNT(&want) == CPU_COUNT(&have)) return;
         for (std::thread &t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want);
     }
-    static constexpr long kSpinUs = 300;
+public:
+    static constexpr long kSpinUsDefault = 300;
+private:
+    std::atomic<long> spin_us_{kSpinUsDefault};
     static void cpu_relax()
     {
 #if defined(__x86_64__) || defined(__i386__)
@@ -180,7 +187,8 @@ private:
             while ((now = generation_.load(std::memory_order_acquire)) == seen) {
                 cpu_relax();
                 if ((++polls & 255u) == 0 &&
-                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinUs) {
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >=
+                        spin_us_.load(std::memory_order_relaxed)) {
                     std::unique_lock<std::mutex> l(m_);
                     parked_.fetch_add(1, std::memory_order_release);
                     wake_.wait(l, [&] { return generation_.load(std::memory_order_acquire) != seen; });
@@ -327,6 +335,7 @@ struct h263mi_batch {
     std::vector<bits::ParserContext> parser_ctx;
     std::vector<bits::ParsedPicture> parsed;
     std::unique_ptr<WorkerPool> pool;          // host threads of the entry points that take host data
+    long pool_spin_us = WorkerPool::kSpinUsDefault;    // (HostThreadPlan::spin_us of the call that is being packed)
     WorkerPool &workers(unsigned want)
     {
         if (!pool || pool->size() < want) pool.reset(new WorkerPool(want - 1));
@@ -1224,7 +1233,7 @@ static int batch_submit_host(h263mi_batch *b, uint8_t picture_type, const h263mi
         pack(0, b->n, 1);
     } else {
         // (thread t packs the streams t, t + T, ...: the ones it has just parsed, see StreamDeal)
-        b->workers(n_thr).run(n_thr, [&](unsigned t) { pack(t, b->n, n_thr); });
+        b->workers(n_thr).run(n_thr, [&](unsigned t) { pack(t, b->n, n_thr); }, b->pool_spin_us);
     }
     if (!offsets_ok.load() || !records_ok.load()) return H263MI_ERR_INVALID_ARGUMENT;      // nothing has been queued yet
     const auto t_enq0 = std::chrono::steady_clock::now();
@@ -1344,28 +1353,69 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type, const
 
 }  // extern "C"
 
-// threads the parser tasks may use when the caller does not say: the hardware threads, the affinity mask and the CPU
-// quota of the container, whichever is smallest (more runnable threads than the quota allows only get throttled: 16
-// parser threads beat 128 on a 16-CPU quota, tools/probes/cpu_scaling.py)
-static uint32_t default_host_threads()
+// What the parser tasks of a call may use.  Two different limits:
+//   * CPUs: the hardware threads and the affinity mask -- more runnable threads than that only take turns;
+//   * CPU TIME: a container's quota (cgroup cpu.max: so many CPU-seconds per second, on a host that may have many more CPUs).
+//     A quota does not limit how many threads run at once, it limits what they use together -- and a worker that spins for
+//     its next task uses its CPU like one that parses.  A call is parse phase + a serial rest (packing, queueing, the caller),
+//     so `quota` spinning threads hold the whole quota while a fifth of it does nothing; more than `quota` spinning threads
+//     overdraw it and the kernel freezes the process for the rest of the scheduler period (32 spinning threads on a 16-CPU
+//     quota: 72 k pictures/s end to end instead of 106 k).  Threads that PARK the moment they run out of work use what they
+//     parse with: then half as many threads again as the quota has CPUs shorten the parse phase (64 streams: 3 pictures per
+//     thread instead of 4) inside the same CPU time: 106 k -> 115-118 k pictures/s on the GPU boxes (16-CPU quota on a
+//     256-thread host; profiles/r05_x_host_thread_plan.txt).  Beyond that the wake-ups cost more than the shorter phase gives.
+// The launcher's LOCAL_WORLD_SIZE (torch.distributed.run, mpirun wrappers) divides both limits: the ranks of one job that
+// share a node share its CPUs.
+struct HostThreadPlan {
+    uint32_t threads;      // parser threads of a call
+    long spin_us;          // how long an idle worker spins before it parks
+    uint32_t cpus;         // CPUs the process may run on at once (hardware, affinity; per rank)
+    uint32_t quota_cpus;   // CPU-time quota in CPUs (per rank), 0 = none
+};
+static void host_cpu_limits(uint32_t &cpus, uint32_t &quota_cpus)
 {
-    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpus = std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<uint32_t>(n, (uint32_t)std::max(1, CPU_COUNT(&set)));
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min<uint32_t>(cpus, (uint32_t)std::max(1, CPU_COUNT(&set)));
+    quota_cpus = 0;
+    const char *cpu_max = getenv("H263MI_CGROUP_CPU_MAX");       // (tests: a file in the format of cgroup v2's cpu.max)
+    if (FILE *f = fopen(cpu_max ? cpu_max : "/sys/fs/cgroup/cpu.max", "r")) {
         char quota[32];
         long period = 0;
         if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
-            n = std::min<uint32_t>(n, (uint32_t)std::max(1L, atol(quota) / period));
+            quota_cpus = (uint32_t)std::max(1L, atol(quota) / period);
         fclose(f);
     }
-    // ranks of one job that share the node share its CPUs: the launcher's LOCAL_WORLD_SIZE (torch.distributed.run, mpirun
-    // wrappers) divides the budget, so that 8 ranks do not start 8 x the quota in parser threads
     if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {
         const long ranks = atol(lw);
-        if (ranks > 1) n = std::max<uint32_t>(1u, n / (uint32_t)ranks);
+        if (ranks > 1) {
+            cpus = std::max<uint32_t>(1u, cpus / (uint32_t)ranks);
+            if (quota_cpus) quota_cpus = std::max<uint32_t>(1u, quota_cpus / (uint32_t)ranks);
+        }
     }
-    return n;
+}
+// n_tasks: the streams of the call; requested: the caller's n_threads (0 = choose)
+static HostThreadPlan host_thread_plan(uint32_t n_tasks, uint32_t requested)
+{
+    HostThreadPlan p{};
+    host_cpu_limits(p.cpus, p.quota_cpus);
+    const bool quota_binds = p.quota_cpus && p.quota_cpus < p.cpus;
+    static const bool oversubscribe = !(getenv("H263MI_QUOTA_OVERSUBSCRIBE") && getenv("H263MI_QUOTA_OVERSUBSCRIBE")[0] == '0');
+    if (requested) {
+        p.threads = requested;
+    } else if (quota_binds && oversubscribe) {
+        // the fewest threads that give the rounds of (quota + quota / 2) threads: 64 streams on a 16-CPU quota -> 3 rounds -> 22
+        const uint32_t cap = std::min(p.cpus, p.quota_cpus + p.quota_cpus / 2);
+        const uint32_t rounds = (n_tasks + cap - 1) / std::max(1u, cap);
+        p.threads = rounds ? (n_tasks + rounds - 1) / rounds : 1;
+    } else {
+        p.threads = quota_binds ? p.quota_cpus : p.cpus;
+    }
+    p.threads = std::max(1u, std::min({p.threads, n_tasks ? n_tasks : 1u, 256u}));
+    // more threads than the quota pays for: they must not spin
+    p.spin_us = (quota_binds && p.threads > p.quota_cpus) ? 0 : WorkerPool::kSpinUsDefault;
+    if (const char *e = getenv("H263MI_SPIN_US")) p.spin_us = atol(e);            // (probes)
+    return p;
 }
 
 // N x decode_next_picture.  stream_rc == nullptr: all or nothing (any stream's error fails the call, nothing changes).
@@ -1428,7 +1478,9 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     const size_t groups_pp = (size_t)recon_tiles_x(b->L) * b->L.mbh;
     // ---- the serial half of decode_next_picture (state.rs:143-427), one stream per task, on n_threads host threads
     std::vector<int> rcs(n, H263MI_OK);
-    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
+    const HostThreadPlan plan = host_thread_plan(n, n_threads);
+    const uint32_t n_thr = plan.threads;
+    b->pool_spin_us = plan.spin_us;
     StreamDeal deal(n);
     auto work = [&](unsigned t) {
         deal.run(t, n_thr, [&](uint32_t i) {
@@ -1459,7 +1511,7 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
     };
     const auto t_parse0 = std::chrono::steady_clock::now();
     if (n_thr == 1) work(0);
-    else b->workers(n_thr).run(n_thr, work);
+    else b->workers(n_thr).run(n_thr, work, plan.spin_us);
     if (b->trace_host) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
         b->host_ms[0] += ms;
@@ -1530,6 +1582,13 @@ static int batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
 }
 
 extern "C" {
+
+uint32_t h263mi_default_parser_threads(uint32_t n_streams, uint32_t *cpu_quota)
+{
+    const HostThreadPlan p = host_thread_plan(n_streams, 0);
+    if (cpu_quota) *cpu_quota = p.quota_cpus;
+    return p.threads;
+}
 
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads)
@@ -1870,7 +1929,8 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
     // ---- the serial half of decode_next_picture (state.rs:143-427) per stream, on the host threads
     static const bool mixed_sparse = !(getenv("H263MI_SPARSE_RECORDS") && getenv("H263MI_SPARSE_RECORDS")[0] == '0');
     std::vector<int> rcs(n, H263MI_OK);
-    const uint32_t n_thr = std::max(1u, std::min({n_threads ? n_threads : default_host_threads(), n, 256u}));
+    const HostThreadPlan plan = host_thread_plan(n, n_threads);
+    const uint32_t n_thr = plan.threads;
     StreamDeal deal(n);
     auto work = [&](unsigned t) {
         deal.run(t, n_thr, [&](uint32_t i) {
@@ -1885,7 +1945,7 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
         });
     };
     if (n_thr == 1) work(0);
-    else m->workers(n_thr).run(n_thr, work);
+    else m->workers(n_thr).run(n_thr, work, plan.spin_us);
 
     // ---- which size each picture has; what must be refused before anything is queued
     std::vector<int> target(n, -1);

@@ -75,6 +75,7 @@ EXPORTS = [
     "h263mi_device_count", "h263mi_device_malloc", "h263mi_device_free", "h263mi_device_memcpy_h2d",
     "h263mi_device_memcpy_d2h", "h263mi_device_synchronize",
     "h263mi_synth_picture_host", "h263mi_synth_batch_device", "h263mi_synth_batch_device_strided",
+    "h263mi_default_parser_threads",
     "h263mi_render_rgba_pinned", "h263mi_host_alloc", "h263mi_host_free", "h263mi_host_register", "h263mi_host_unregister",
     "h263mi_debug_fail_nth_hip_call",
     "h263mi_mixed_create", "h263mi_mixed_destroy", "h263mi_mixed_decode_next_pictures", "h263mi_mixed_sync",
@@ -207,6 +208,8 @@ def lib():
                                                 C.POINTER(sz)]
         L.h263mi_synth_batch_device_strided.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, u32, vp, vp, sz, vp,
                                                         C.POINTER(sz)]
+        L.h263mi_default_parser_threads.restype = u32
+        L.h263mi_default_parser_threads.argtypes = [u32, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -708,6 +711,14 @@ def synth_picture_host(kind, width, height, stream_id, frame_idx):
     _check(lib().h263mi_synth_picture_host(kind, width, height, stream_id, frame_idx, _p(mbs), _p(coeffs), total * 6,
                                            C.byref(n)), "synth_picture_host")
     return mbs, coeffs[:n.value].copy()
+
+
+def default_parser_threads(n_streams):
+    """(threads, cpu_quota): the parser threads a batch call with n_threads = 0 uses for n_streams streams, and the CPU-time
+    quota (in CPUs, 0 = none) that choice was made under (h263mi_default_parser_threads)."""
+    q = C.c_uint32(0)
+    t = lib().h263mi_default_parser_threads(n_streams, C.byref(q))
+    return int(t), int(q.value)
 
 
 def synth_batch_device(kind, width, height, n_streams, first_stream_id, frame_idx, d_mbs, d_coeffs, capacity_blocks,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define H263MI_ABI_VERSION 5
+#define H263MI_ABI_VERSION 6
 
 /* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
 #define H263MI_OK                                  0
@@ -360,8 +360,7 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
 /*
  * N x H263State::decode_next_picture(reader) (state.rs:138-141) in one call: data[s] / len[s] hold one coded picture
  * of stream s (what Ruffle hands one reader per FLV video tag).  The serial parse of each stream (state.rs:143-427)
- * runs on `n_threads` host threads (0 = what this process may use: hardware threads, affinity mask and the container's
- * CPU quota, whichever is smallest, divided by LOCAL_WORLD_SIZE when a launcher exports it), one stream per task; the records of all streams
+ * runs on `n_threads` host threads (0 = h263mi_default_parser_threads(n_streams, ...), below), one stream per task; the records of all streams
  * then cross to the device as events (h263mi_batch_submit_host_events) and ONE launch decodes them: k_recon, or -- on a
  * H263MI_CFG_PIPELINE_POST batch through the _ex form -- k_frame, which also post-processes the previous picture.
  * consumed[s] (may be NULL) receives the bytes used.  decoder_options as for h263mi_state_new.  If any stream fails
@@ -378,6 +377,17 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  * gets the parser's end-of-stream error and, all or nothing, the call fails with it); "no picture for this stream" exists
  * in the _ex form only.
  */
+/*
+ * (ABI 6) The parser threads a call with n_threads = 0 uses for `n_streams` streams.  Without a CPU-time quota: the CPUs the process
+ * may run on (hardware threads, affinity mask).  Under a container's quota (cgroup cpu.max of Q CPUs on a host with more):
+ * the fewest threads that give the rounds of Q + Q/2 threads -- 22 for 64 streams on 16 CPUs -- and the workers PARK as soon
+ * as they run out of work instead of spinning for the next call: a quota limits CPU time, not threads, and a spinning worker
+ * spends it like a parsing one (h263-rs_amd/csrc/backend.cpp: HostThreadPlan; H263MI_QUOTA_OVERSUBSCRIBE=0: Q threads).  A
+ * caller that passes more threads than the quota has CPUs gets the parking workers too.  Both limits are divided by
+ * LOCAL_WORLD_SIZE when a launcher exports it (the ranks of a job share the node).  *cpu_quota (may be NULL) receives Q, 0 =
+ * no quota.
+ */
+uint32_t h263mi_default_parser_threads(uint32_t n_streams, uint32_t *cpu_quota);
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads);
 /*

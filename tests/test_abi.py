@@ -3,6 +3,7 @@ include/h263mi.h declares, shares its record layout with the oracle, and -- with
 container -- fails loudly instead of falling back to a CPU path.  No compute calls here."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -30,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "include/h263mi.h declares %s but libh263mi.so does not export it" % name
     assert declared == set(h263mi.EXPORTS), declared ^ set(h263mi.EXPORTS)
-    assert L.h263mi_abi_version() == 5
+    assert L.h263mi_abi_version() == 6
 
 
 def test_record_layout_matches_header_and_oracle():
@@ -150,3 +151,43 @@ def test_committed_traffic_figure_belongs_to_the_kernel_sources_in_the_tree():
         "profiles/traffic_latest.json is from other kernel code: re-run tools/prof_final.sh and copy its traffic.json"
     k = tr["kernels"]["k_frame"]
     assert k["launches_sampled"] >= 60 and 0.9e9 < k["hbm_bytes_per_launch"] < 1.3e9
+
+
+_PLAN_PROBE = r"""
+import sys
+sys.path.insert(0, %r)
+import h263mi
+print(";".join("%%d,%%d" %% h263mi.default_parser_threads(n) for n in (64, 5, 1, 1000)))
+"""
+
+
+def test_default_parser_threads_follow_the_cpu_time_quota(tmp_path):
+    """h263mi_default_parser_threads (include/h263mi.h): without a quota, or under one that is no tighter than the CPUs the
+    process may run on, the CPUs; under a binding quota of Q CPUs the fewest threads that give the rounds of Q + Q/2 threads;
+    LOCAL_WORLD_SIZE divides both limits; H263MI_QUOTA_OVERSUBSCRIBE=0 gives Q."""
+    import subprocess
+    cpus = len(os.sched_getaffinity(0))
+    if cpus < 4:
+        pytest.skip("needs 4 CPUs in the affinity mask")
+
+    def plan(quota_text, **env):
+        f = tmp_path / "cpu.max"
+        f.write_text(quota_text)
+        e = dict(os.environ, H263MI_CGROUP_CPU_MAX=str(f))
+        e.pop("LOCAL_WORLD_SIZE", None)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", _PLAN_PROBE % os.path.join(ROOT, "h263-rs_amd")], env=e, capture_output=True,
+                             text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [tuple(int(v) for v in item.split(",")) for item in out.stdout.strip().split(";")]
+
+    # no quota: the CPUs, never more threads than streams
+    assert plan("max 100000") == [(min(cpus, 64), 0), (min(cpus, 5), 0), (1, 0), (min(cpus, 1000), 0)]
+    # a quota that does not bind (more CPU time than CPUs): the same, the quota reported
+    q = 2 * cpus
+    assert plan("%d 100000" % (q * 100000)) == [(min(cpus, 64), q), (min(cpus, 5), q), (1, q), (min(cpus, 1000), q)]
+    # a binding quota of 2 CPUs: up to 3 threads; 64 streams -> 22 rounds -> 3 threads; 5 streams -> 2 rounds -> 3; 1 stream -> 1
+    assert plan("200000 100000") == [(3, 2), (3, 2), (1, 2), (3, 2)]
+    assert plan("200000 100000", H263MI_QUOTA_OVERSUBSCRIBE="0") == [(2, 2), (2, 2), (1, 2), (2, 2)]
+    # two ranks share the node: half the CPUs and half the quota each
+    assert plan("400000 100000", LOCAL_WORLD_SIZE="2") == [(3, 2), (3, 2), (1, 2), (3, 2)]

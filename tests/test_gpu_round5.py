@@ -421,3 +421,44 @@ def test_sparse_and_dense_record_transport_decode_alike(sparse, direct):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, H263MI_SPARSE_RECORDS=sparse, H263MI_DIRECT_WORDS=direct),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sparse-probe-ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+# ---------------------------------------------------------------------------------------------
+# parser threads that PARK between calls (HostThreadPlan: what a call gets under a CPU-time quota when it runs more threads than
+# the quota has CPUs).  Forced here with H263MI_SPIN_US=0, whatever the host's quota is: 40 threads for 48 streams, woken and
+# parked once per call over a GOP, every stream against the oracle.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_parked_parser_threads_decode_like_spinning_ones():
+    import recgen
+    import sorenson_enc as enc
+    from test_bitstream_e2e import make_codable
+    w, h, n, q = 176, 144, 48, 9
+    os.environ["H263MI_SPIN_US"] = "0"
+    try:
+        b = h263mi.Batch(n, w, h, pipeline_post=True)
+        d_rgba = h263mi.DeviceBuffer(n * w * h * 4)
+        refs = [None] * n
+        for f in range(7):
+            datas = []
+            for s in range(n):
+                if f == 0:
+                    mbs, co = recgen.realistic_intra_picture(w, h, 500 + s % 5, quant=q)
+                else:
+                    mbs, co = recgen.realistic_inter_picture(w, h, 1000 * f + s % 7, p_skip=0.5, p_coded=0.25, quant=q)
+                mbs = make_codable(mbs, q, s % 5 + f, 0 if f == 0 else 1)
+                datas.append(enc.encode_picture(w, h, 0 if f == 0 else 1, q, mbs, co, temporal_reference=f))
+                rc, refs[s] = orc.decode_picture(w, h, mbs, co, None if f == 0 else refs[s])
+                assert rc == 0
+            used, rcs = b.decode_next_pictures_ex(datas, n_threads=40, strength=4, d_rgba=d_rgba.ptr)
+            assert not any(rcs), rcs
+            assert all(len(d) - 1 <= u <= len(d) for u, d in zip(used, datas))     # (whole bytes drained, reader.rs commit())
+        b.sync()
+        cw = (w + 1) // 2
+        for s in range(n):
+            assert all((g == e).all() for g, e in zip(b.copy_yuv(s), refs[s])), s
+            filt = tuple(orc.deblock(p, pw, 4) for p, pw in zip(refs[s], (w, cw, cw)))
+            assert (d_rgba.download(w * h * 4, s * w * h * 4) == orc.yuv420_to_rgba(*filt, w)).all(), s
+        b.close()
+    finally:
+        del os.environ["H263MI_SPIN_US"]

@@ -442,9 +442,13 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
     # the stages on their own: the same call with one parser thread
     p_bytes = sum(len(p) for p in streams[0][1:])
     i_bytes = len(streams[0][0])
-    t1 = time.perf_counter()
+    # (the first GOP behind the many-thread run finds every stream's buffers in other cores' caches: best of the two behind it)
     run_gop(1)
-    dt1 = time.perf_counter() - t1
+    dt1 = 1e9
+    for _ in range(2):
+        t1 = time.perf_counter()
+        run_gop(1)
+        dt1 = min(dt1, time.perf_counter() - t1)
     batch.close()
     pics = n * len(order) * reps
     pps = pics / dt

@@ -108,6 +108,11 @@ enum : uint32_t {
     STREAM_RECON_SKIP = 4u,   // no picture for this stream in this call: its frames are not touched
     STREAM_POST_SET1 = 8u,    // the picture to post-process lives in frame set 1
     STREAM_POST_SKIP = 16u,   // nothing to post-process for this stream
+    // bits 8..11: the post-filter strength of the stream's picture, 0 (no deblocking) .. 12 -- the consumer picks it per picture
+    // (QUANT_TO_STRENGTH of the picture's quantiser, deblock.rs:5-8): with per-stream words in use every post-processing wave
+    // takes its strength from here, whether or not the streams' strengths differ
+    STREAM_STRENGTH_SHIFT = 8u,
+    STREAM_STRENGTH_MASK = 15u,
 };
 
 // ---------------------------------------------------------------------------
@@ -157,7 +162,7 @@ struct PostArgs {
     uint8_t *rgba;               // n_pictures * w*h*4, tightly packed, or nullptr
     uint8_t *planes_out;         // n_pictures * (w*h + 2*cw*ch) tightly packed deblocked planes, or nullptr
     uint32_t n_pictures;
-    uint32_t strength;           // 0 = no deblocking
+    uint32_t strength;           // 0 = no deblocking (with stream_state: unused, the strength is in the stream's word)
     uint32_t tiles_x, tiles_y;
     uint32_t luma_only;          // standalone deblock() of a single plane
     uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x) (set by the launcher)

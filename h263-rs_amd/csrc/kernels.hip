@@ -515,6 +515,7 @@ __device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int 
         const uint32_t st = a0.stream_state[pic];
         if (st & STREAM_POST_SKIP) return;
         a.frames = a0.frame_set[(st & STREAM_POST_SET1) ? 1 : 0];
+        a.strength = (st >> STREAM_STRENGTH_SHIFT) & STREAM_STRENGTH_MASK;      // this picture's own (deblock.rs:5-8)
         // per-stream output buffers: the phases address picture `pic` at a.rgba + pic * w*h*4 -- hand them the base that
         // puts it at its own pointer (uniform: two scalar loads)
         if (a0.rgba_ptrs) a.rgba = a0.rgba_ptrs[pic] - (size_t)pic * a0.L.width * a0.L.height * 4u;

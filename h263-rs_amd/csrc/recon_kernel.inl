@@ -307,6 +307,10 @@ H263_DEV BasisPtr basis_table_sixteenth()
 }
 H263_DEV f32x2 basis_pair(BasisPtr B, int f, int ip) { f32x2 r = {B[f][2 * ip], B[f][2 * ip + 1]}; return r; }
 
+}  // namespace h263mi
+#include "mutants.h"         // the arithmetic mutants of the tests (compile-time off in the product)
+namespace h263mi {
+
 // idct_1d (idct.rs:52-65): out[i] = sum over f, in order, of in[f] * B[f][i].  The leading
 // "0.0 +" is dropped: it can only change the sign of a zero, which never reaches the integer result.
 // Only the terms f < n are accumulated: the caller guarantees in[f] == 0 for f >= n, and adding a
@@ -319,20 +323,10 @@ H263_DEV void idct_1d_pairs(BasisPtr B, const float in[8], f32x2 out[4], int n, 
     // (idct.rs:40: BASIS_TABLE[0][i] = 0.70710677 for every i)
     // (raw_scale: what `in` is scaled by relative to the table -- a power of two; 1 / raw_scale takes it out again)
     const f32x2 first = splat2(in[0]) * splat2(first_term_raw ? raw_scale : B[0][0]);
-#if defined(H263MI_MUTATE_PAIRWISE)
-    // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the eight rounded products summed as a balanced
-    // tree instead of in the order of the frequency index.  The parity suite must notice.
-#pragma unroll
-    for (int ip = 0; ip < 4; ip++) {
-        f32x2 pr[8];
-        pr[0] = first;
-#pragma unroll
-        for (int f = 1; f < 8; f++) pr[f] = splat2(in[f]) * basis_pair(B, f, ip);
-        out[ip] = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+    if (mutants::kPairwise) {                        // (compile-time false in the product: mutants.h)
+        mutants::idct_1d_pairwise(B, in, out, first);
+        return;
     }
-    (void)n;
-    return;
-#endif
     if (n <= 1) {                                    // uniform
 #pragma unroll
         for (int ip = 0; ip < 4; ip++) out[ip] = first;
@@ -390,12 +384,7 @@ H263_DEV uint32_t dequant_pair_i16(uint32_t levels, uint32_t two_q2, uint32_t qm
     asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]" : "=&v"(sg) : "v"(levels));   // -1, 0 or +1
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2 << 4));
     asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2 << 4), "v"(t));
-#if defined(H263MI_MUTATE_DEQUANT_SATURATION)
-    // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the saturated values keep their low bits, so a LEVEL
-    // beyond the clamp comes out as 2047.9375 instead of 2047.  The every-LEVEL-at-every-quantiser test must notice.
-    return v;
-#endif
-    return v & 0xfff0fff0u;
+    return mutants::kDequantSaturation ? v : (v & 0xfff0fff0u);       // (mutants.h: compile-time false in the product)
 #else
     uint32_t out = 0;
     for (int h = 0; h < 2; h++) {
@@ -421,13 +410,8 @@ H263_DEV uint32_t dequant_pair_wrap(uint32_t levels, uint32_t two_q2, uint32_t q
     uint32_t sg, t, v;
     asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]" : "=&v"(sg) : "v"(levels));   // -1, 0 or +1
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(sg), "v"(qmp2));
-#if defined(H263MI_MUTATE_DEQUANT_WRAP)
-    // MUTANT BUILD (tests/test_gpu_mutation.py), never the product: the multiply-add saturates, i.e. the mathematical
-    // product is clamped where the reference clamps the wrapped one.  The wide-LEVEL test must notice.
-    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
-#else
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
-#endif
+    if (mutants::kDequantWrap) asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));   // (mutants.h)
+    else asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(v) : "v"(levels), "v"(two_q2), "v"(t));
     return pk_min_i16(pk_max_i16(v, 0xf800f800u), 0x07ff07ffu);
 #else
     uint32_t out = 0;

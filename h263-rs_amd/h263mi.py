@@ -81,7 +81,13 @@ EXPORTS = [
     "h263mi_mixed_create", "h263mi_mixed_destroy", "h263mi_mixed_decode_next_pictures", "h263mi_mixed_sync",
     "h263mi_mixed_stream_size", "h263mi_mixed_size_classes", "h263mi_mixed_set_memory_limit",
     "h263mi_mixed_frame_store_bytes", "h263mi_mixed_copy_yuv", "h263mi_mixed_reset_stream",
+    # ABI 7: one post-filter strength per stream, explicit host share, NUMA placement report
+    "h263mi_batch_decode_ps", "h263mi_batch_decode_events_ps", "h263mi_batch_render_rgba_ps",
+    "h263mi_batch_decode_next_pictures_ps", "h263mi_mixed_decode_next_pictures_ps",
+    "h263mi_set_ranks_per_node", "h263mi_batch_host_placement",
 ]
+STRENGTH_FROM_HEADER = 0xFF
+CFG_OVERLAP_POST, CFG_PIPELINE_POST, CFG_TRUSTED_ARRAYS = 1, 2, 4
 
 
 class H263Error(RuntimeError):
@@ -208,6 +214,14 @@ def lib():
                                                 C.POINTER(sz)]
         L.h263mi_synth_batch_device_strided.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, u32, vp, vp, sz, vp,
                                                         C.POINTER(sz)]
+        L.h263mi_batch_decode_ps.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp, vp]
+        L.h263mi_batch_decode_events_ps.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8, vp, vp, vp]
+        L.h263mi_batch_render_rgba_ps.argtypes = [vp, u8, vp, vp, vp]
+        L.h263mi_batch_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp]
+        L.h263mi_mixed_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp, vp]
+        L.h263mi_set_ranks_per_node.argtypes = [u32]
+        L.h263mi_set_ranks_per_node.restype = None
+        L.h263mi_batch_host_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), vp, u32]
         L.h263mi_default_parser_threads.restype = u32
         L.h263mi_default_parser_threads.argtypes = [u32, C.POINTER(u32)]
         _lib = L
@@ -469,9 +483,13 @@ class DeviceBuffer:
 class Batch:
     """N independent streams advancing in lock step on one GPU (h263mi_batch_*)."""
 
-    def __init__(self, n_streams, width, height, device_id=0, stream=None, overlap_post=False, pipeline_post=False):
+    def __init__(self, n_streams, width, height, device_id=0, stream=None, overlap_post=False, pipeline_post=False,
+                 trusted_arrays=False):
+        """trusted_arrays: H263MI_CFG_TRUSTED_ARRAYS -- the caller vouches for the device arrays of submit / decode /
+        decode_events; the default (ABI 7) bounds every one of them"""
         self.n, self.width, self.height, self.device_id = n_streams, width, height, device_id
-        self._cfg = BackendCfg(device_id, (1 if overlap_post else 0) | (2 if pipeline_post else 0), stream)
+        self._cfg = BackendCfg(device_id, (CFG_OVERLAP_POST if overlap_post else 0) | (CFG_PIPELINE_POST if pipeline_post else 0) |
+                               (CFG_TRUSTED_ARRAYS if trusted_arrays else 0), stream)
         self._h = C.c_void_p()
         _check(lib().h263mi_batch_create(n_streams, width, height, C.byref(self._cfg), C.byref(self._h)),
                "batch_create")
@@ -491,21 +509,30 @@ class Batch:
     def submit(self, picture_type, d_mbs, d_coeffs, d_coeff_base=None):
         _check(lib().h263mi_batch_submit(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base), "batch_submit")
 
+    def _strengths(self, strengths):
+        """None, or one post-filter strength per stream -> (keep-alive array, pointer) for the *_ps entry points"""
+        if strengths is None:
+            return None, None
+        arr = np.ascontiguousarray(strengths, np.uint8)
+        assert arr.size == self.n
+        return arr, _p(arr)
+
     def decode(self, picture_type, d_mbs, d_coeffs, d_coeff_base=None, coeff_pool_blocks=0, strength=0, d_rgba=None,
-               d_deblocked=None):
-        """submit + render_rgba in one call (h263mi_batch_decode)"""
-        _check(lib().h263mi_batch_decode(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength,
-                                         d_rgba, d_deblocked), "batch_decode")
+               d_deblocked=None, strengths=None):
+        """submit + render_rgba in one call (h263mi_batch_decode[_ps]).  strengths: one value per stream (ABI 7)"""
+        keep, ps = self._strengths(strengths)
+        _check(lib().h263mi_batch_decode_ps(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength, ps,
+                                            d_rgba, d_deblocked), "batch_decode")
 
     def decode_events(self, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base=None, coeff_pool_blocks=0,
-                      strength=0, d_rgba=None, d_deblocked=None, n_events=0):
-        """h263mi_batch_decode_events: decode with the coefficients as sparse events in device memory.  n_events: words in
-        d_events.  Given it, a block whose bounds do not ascend or reach beyond it is not read and its picture is rejected.
-        0 = not told: the caller VOUCHES for d_block_first_event / d_events and the device checks NOTHING (include/h263mi.h)
-        -- unvalidated arrays can then make a wave read up to 64 words beyond a block's first event.  Pass the real count
-        unless the arrays come from a source that is valid by construction."""
-        _check(lib().h263mi_batch_decode_events(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
-                                                coeff_pool_blocks, n_events, strength, d_rgba, d_deblocked), "batch_decode_events")
+                      strength=0, d_rgba=None, d_deblocked=None, n_events=0, strengths=None):
+        """h263mi_batch_decode_events[_ps]: decode with the coefficients as sparse events in device memory.  n_events: words
+        in d_events, coeff_pool_blocks: blocks in the pool; a block whose bounds do not ascend or reach beyond them is not
+        read and its picture is rejected.  0 = not told: the library bounds the arrays by the allocations they lie in (ABI 7)
+        -- unless the batch was made with trusted_arrays, where 0 means the caller vouches and nothing is checked."""
+        keep, ps = self._strengths(strengths)
+        _check(lib().h263mi_batch_decode_events_ps(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
+                                                   coeff_pool_blocks, n_events, strength, ps, d_rgba, d_deblocked), "batch_decode_events")
 
     def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None):
         """one coded picture per stream (bytes-like objects) through the host parser threads and the GPU; returns the
@@ -528,15 +555,25 @@ class Batch:
         return pd, ln, keep
 
     def decode_next_pictures_ex(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, prepared=None,
-                                strength=0, d_rgba=None, d_deblocked=None):
-        """h263mi_batch_decode_next_pictures_ex: every stream its own H263State.  Returns (bytes consumed per stream,
-        error code per stream: 0 = decoded or no data)."""
+                                strength=0, d_rgba=None, d_deblocked=None, strengths=None):
+        """h263mi_batch_decode_next_pictures_ex / _ps: every stream its own H263State.  strength may be STRENGTH_FROM_HEADER
+        (each picture with QUANT_TO_STRENGTH[its pquant] when its header sets USE_DEBLOCKER, else 0); strengths: one value
+        per stream.  Returns (bytes consumed per stream, error code per stream: 0 = decoded or no data)."""
         pd, ln, keep = prepared if prepared is not None else self.prepare_pictures(data_list)
         used = (C.c_size_t * self.n)()
         rcs = (C.c_int * self.n)()
-        _check(lib().h263mi_batch_decode_next_pictures_ex(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength,
+        keep_s, ps = self._strengths(strengths)
+        _check(lib().h263mi_batch_decode_next_pictures_ps(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength, ps,
                                                           d_rgba, d_deblocked), "batch_decode_next_pictures_ex")
         return list(used), list(rcs)
+
+    def host_placement(self):
+        """h263mi_batch_host_placement: (NUMA node of the device, node the pinned staging memory lies on, CPUs the host
+        threads are confined to) -- -1 / -1 / [] where unknown or not made yet"""
+        dn, sn, k = C.c_int(-1), C.c_int(-1), C.c_uint32(0)
+        cpus = (C.c_uint16 * 1024)()
+        _check(lib().h263mi_batch_host_placement(self._h, C.byref(dn), C.byref(sn), C.byref(k), cpus, 1024), "host_placement")
+        return dn.value, sn.value, [int(cpus[i]) for i in range(min(k.value, 1024))]
 
     def sync_streams(self):
         """h263mi_batch_sync_streams: the device's verdict per stream (0 or an error code); never raises for those"""
@@ -581,8 +618,9 @@ class Batch:
         ne = (C.c_uint32 * n)(*[len(e) for e in evs])
         _check(lib().h263mi_batch_submit_host_events(self._h, picture_type, pm, nm, pf, nb, pe, ne), "batch_submit_host_events")
 
-    def render_rgba(self, strength, d_rgba, d_deblocked=None):
-        _check(lib().h263mi_batch_render_rgba(self._h, strength, d_rgba, d_deblocked), "batch_render_rgba")
+    def render_rgba(self, strength, d_rgba, d_deblocked=None, strengths=None):
+        keep, ps = self._strengths(strengths)
+        _check(lib().h263mi_batch_render_rgba_ps(self._h, strength, ps, d_rgba, d_deblocked), "batch_render_rgba")
 
     def sync(self):
         _check(lib().h263mi_batch_sync(self._h), "batch_sync")
@@ -633,7 +671,7 @@ class MixedBatch:
             pass
 
     def decode_next_pictures(self, data_list, decoder_options=SORENSON_SPARK_BITSTREAM, n_threads=0, strength=0, rgba=None,
-                             raise_on_error=True):
+                             raise_on_error=True, strengths=None):
         """data_list: bytes or None per stream; rgba: DeviceBuffer or None per stream (or None: no rendering).
         Returns (bytes consumed, error codes, picture headers) per stream; with raise_on_error=False a call-level error
         does not raise and comes back as a fourth element (the per-stream results are valid either way)."""
@@ -649,7 +687,13 @@ class MixedBatch:
         if rgba is not None:
             ptrs = (C.c_void_p * self.n)(*[(r.ptr.value if hasattr(r.ptr, "value") else r.ptr) if r is not None else None for r in rgba])
             caps = (C.c_size_t * self.n)(*[r.nbytes if r is not None else 0 for r in rgba])
-        rc = lib().h263mi_mixed_decode_next_pictures(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength, ptrs, caps, descs)
+        ps = None
+        if strengths is not None:
+            keep_s = np.ascontiguousarray(strengths, np.uint8)
+            assert keep_s.size == self.n
+            ps = _p(keep_s)
+        rc = lib().h263mi_mixed_decode_next_pictures_ps(self._h, decoder_options, pd, ln, used, n_threads, rcs, strength, ps, ptrs, caps,
+                                                        descs)
         if not raise_on_error:
             return list(used), list(rcs), list(descs), rc
         _check(rc, "mixed_decode_next_pictures")
@@ -711,6 +755,11 @@ def synth_picture_host(kind, width, height, stream_id, frame_idx):
     _check(lib().h263mi_synth_picture_host(kind, width, height, stream_id, frame_idx, _p(mbs), _p(coeffs), total * 6,
                                            C.byref(n)), "synth_picture_host")
     return mbs, coeffs[:n.value].copy()
+
+
+def set_ranks_per_node(ranks):
+    """h263mi_set_ranks_per_node: how many processes share this node's CPUs with this one (0 = back to the environment)"""
+    lib().h263mi_set_ranks_per_node(int(ranks))
 
 
 def default_parser_threads(n_streams):

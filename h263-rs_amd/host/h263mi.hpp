@@ -124,7 +124,10 @@ public:
                                            events.size()));
     }
 
-    // consumer post-processing of the last picture: deblock x3 (strength 0 = off) + BT.601
+    // consumer post-processing of the last picture: deblock x3 (strength 0 = off) + BT.601.
+    // strength = kStrengthFromHeader: what the picture's own header asks for -- QUANT_TO_STRENGTH[as_header().quantizer] when
+    // its USE_DEBLOCKER option is set, else no deblocking (deblock.rs:5-8, picture.rs:61-64, types.rs:94-96, 216)
+    static constexpr uint8_t kStrengthFromHeader = H263MI_STRENGTH_FROM_HEADER;
     std::vector<uint8_t> render_rgba(uint8_t strength) const
     {
         h263mi_frame_view v;
@@ -244,19 +247,22 @@ public:
     // (0 = off) + BT.601 of the picture (on a H263MI_CFG_PIPELINE_POST set: by the time of the next call or of sync()).
     // Throws only for a failure of the call itself; a stream's own error is in Outcome::result and leaves that stream as
     // it was (state.rs:142).
+    // strength: one for every picture of the call, or H263State::kStrengthFromHeader: every picture with what ITS header
+    // asks for (64 streams, 64 quantisers); strengths (optional, ABI 7): the caller's own choice per stream instead.
     Outcome decode_next_pictures(const std::vector<const uint8_t *> &data, const std::vector<size_t> &len, uint8_t strength = 0,
                                  const std::vector<uint8_t *> *d_rgba = nullptr, const std::vector<size_t> *rgba_capacity = nullptr,
-                                 uint32_t n_threads = 0)
+                                 uint32_t n_threads = 0, const std::vector<uint8_t> *strengths = nullptr)
     {
-        if (data.size() != n_ || len.size() != n_ || (d_rgba && (!rgba_capacity || d_rgba->size() != n_ || rgba_capacity->size() != n_)))
+        if (data.size() != n_ || len.size() != n_ || (d_rgba && (!rgba_capacity || d_rgba->size() != n_ || rgba_capacity->size() != n_)) ||
+            (strengths && strengths->size() != n_))
             throw Error(H263MI_ERR_INVALID_ARGUMENT);
         Outcome o;
         o.result.assign(n_, H263MI_OK);
         o.consumed.assign(n_, 0);
         o.headers.assign(n_, h263mi_picture_desc{});
-        check(h263mi_mixed_decode_next_pictures(m_, options_, data.data(), len.data(), o.consumed.data(), n_threads, o.result.data(),
-                                                strength, d_rgba ? d_rgba->data() : nullptr,
-                                                rgba_capacity ? rgba_capacity->data() : nullptr, o.headers.data()));
+        check(h263mi_mixed_decode_next_pictures_ps(m_, options_, data.data(), len.data(), o.consumed.data(), n_threads, o.result.data(),
+                                                   strength, strengths ? strengths->data() : nullptr, d_rgba ? d_rgba->data() : nullptr,
+                                                   rgba_capacity ? rgba_capacity->data() : nullptr, o.headers.data()));
         return o;
     }
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define H263MI_ABI_VERSION 6
+#define H263MI_ABI_VERSION 7
 
 /* ---- error codes: h263/src/error.rs:6-58, one per `Error` variant, in order ---- */
 #define H263MI_OK                                  0
@@ -143,6 +143,14 @@ typedef struct h263mi_picture_desc {
  * renders or decodes on this batch has been followed by a sync); a consumer that reads them in stream order must
  * call h263mi_batch_sync first.  Results are identical to the immediate mode. */
 #define H263MI_CFG_PIPELINE_POST 0x2u
+/* H263MI_CFG_TRUSTED_ARRAYS (batches only, ABI 7): the caller vouches for the DEVICE arrays it hands to h263mi_batch_submit /
+ * _decode / _decode_events.  Without it -- the default -- nothing in those arrays is believed: the sizes the caller gives
+ * (coeff_pool_blocks, n_events) bound what the waves read, a size it does not give (0) is taken from the allocation the
+ * pointer lies in (hipMemGetAddressRange; a pointer the runtime does not know is H263MI_ERR_INVALID_ARGUMENT), and the record
+ * and base arrays must fit theirs.  A coded block outside the pool or an event list whose bounds do not ascend or reach beyond
+ * the events is not read and rejects its stream's picture at the next sync.  The checks cost the 64-stream launch nothing
+ * measurable (bench.py: roofline.trusted_mode); the flag is for callers that cannot afford even the look-up. */
+#define H263MI_CFG_TRUSTED_ARRAYS 0x4u
 typedef struct h263mi_backend_cfg {
     int32_t  device_id;
     uint32_t flags;
@@ -234,7 +242,16 @@ int h263mi_copy_yuv(const h263mi_state *s, uint8_t *y, uint8_t *cb, uint8_t *cr)
  * with `strength` (0 = no deblocking, else 1..12) followed by yuv420_to_rgba(), fused on
  * the device for the last picture; w*h*4 bytes to HOST memory.  The reference planes are
  * not modified (post-filter, deblock.rs:1-2).
+ *
+ * The strength is the consumer's choice PER PICTURE: the reference exports QUANT_TO_STRENGTH for it (deblock.rs:5-8) and
+ * hands out the picture's quantiser and its USE_DEBLOCKER flag through DecodedPicture::as_header (picture.rs:61-64,
+ * types.rs:94-96, 216; set at parser/picture.rs:322).  (ABI 7) Wherever this library has parsed the picture header itself,
+ * `strength` may be H263MI_STRENGTH_FROM_HEADER: the picture is filtered with
+ *     use_deblocker ? h263mi_quant_to_strength[pquant] : 0
+ * of ITS OWN header -- every stream of a batch call with its own value.  Entry points over records (no header in sight)
+ * answer H263MI_ERR_INVALID_ARGUMENT to it; their *_ps forms take one value per stream from the caller instead.
  */
+#define H263MI_STRENGTH_FROM_HEADER 0xFFu
 int h263mi_render_rgba(const h263mi_state *s, uint8_t strength, uint8_t *rgba);
 /*
  * The same into PINNED host memory (ABI 4), for a caller that renders every picture: `rgba` must lie in memory from
@@ -303,7 +320,8 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
  * there; both NULL = reconstruction only).  Knowing both halves up front lets the library order the work so that
  * the reconstructed planes are still on chip when they are filtered and converted.  coeff_pool_blocks is the size of
  * d_coeffs in 64-coefficient blocks: a coded block that would lie outside is not read and makes the next
- * h263mi_batch_sync fail with H263MI_ERR_INVALID_ARGUMENT (0 = size unknown, nothing is checked).
+ * h263mi_batch_sync fail with H263MI_ERR_INVALID_ARGUMENT.  0 = not told: the pool then ends where the allocation d_coeffs
+ * lies in ends (ABI 7; on a H263MI_CFG_TRUSTED_ARRAYS batch: nothing is checked).
  *
  * Errors the device detects (this one; an inter macroblock without a reference picture) surface at the next
  * h263mi_batch_sync, per stream (h263mi_batch_sync_streams says which).  A stream whose picture was rejected forgets
@@ -317,6 +335,14 @@ int h263mi_batch_submit(h263mi_batch *b, uint8_t picture_type,
 int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
                         const h263mi_mb_record *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
                         uint64_t coeff_pool_blocks, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
+/* (ABI 7) ... with one post-filter strength PER STREAM: strengths (HOST array of n_streams values 0..12, or NULL = `strength`
+ * for every stream, as above).  The streams of a batch are independent: each picture has its own quantiser, so each has its
+ * own strength (deblock.rs:5-8).  The post-processing waves of a launch read their picture's value with one scalar load;
+ * 0 = that picture is converted without deblocking. */
+int h263mi_batch_decode_ps(h263mi_batch *b, uint8_t picture_type,
+                           const h263mi_mb_record *d_mbs, const int16_t *d_coeffs, const uint64_t *d_coeff_base,
+                           uint64_t coeff_pool_blocks, uint8_t strength, const uint8_t *strengths, uint8_t *d_rgba,
+                           uint8_t *d_deblocked);
 /* h263mi_batch_decode with sparse coefficient transport (see h263mi_submit_picture_events), everything in DEVICE memory:
  * d_block_first_event[k], [k + 1] bound the events of coded block k of the pool (k = d_coeff_base[s] + the stream's own
  * block number; the array has one entry more than the pool has blocks), d_events holds `level << 16 | x + 8 * y` per
@@ -324,14 +350,21 @@ int h263mi_batch_decode(h263mi_batch *b, uint8_t picture_type,
  * is the form the host parser emits and h263mi_batch_decode_next_pictures copies to the device: the reconstruction
  * waves read it as it is.
  * n_events (ABI 4): the number of words d_events holds, or 0 = not told.  The device arrays are the caller's and nobody
- * has validated them; when n_events is given, a block whose bounds are not ascending or reach beyond it is NOT read and
- * the stream's picture is rejected at the next sync (H263MI_ERR_INVALID_ARGUMENT, like a coded block outside the pool).
- * With 0 the caller vouches for its arrays: the bounds are used as they are and the waves spend nothing on them.
+ * has validated them: a block whose bounds are not ascending or reach beyond n_events is NOT read and the stream's picture
+ * is rejected at the next sync (H263MI_ERR_INVALID_ARGUMENT, like a coded block outside the pool).  With 0 (ABI 7) the
+ * events end where the allocation d_events lies in ends, and the pool has as many blocks as the allocation of
+ * d_block_first_event has entries, less one: whatever the arrays hold, no wave reads outside memory the caller owns.  Only
+ * on a H263MI_CFG_TRUSTED_ARRAYS batch does 0 mean "the caller vouches": the bounds are then used as they are.
  * At most 0xffffff00 words (event indices are 32-bit on the device; more is H263MI_ERR_INVALID_ARGUMENT). */
 int h263mi_batch_decode_events(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
                                const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
                                uint64_t coeff_pool_blocks, uint64_t n_events, uint8_t strength, uint8_t *d_rgba,
                                uint8_t *d_deblocked);
+/* (ABI 7) ... with one strength per stream (see h263mi_batch_decode_ps) */
+int h263mi_batch_decode_events_ps(h263mi_batch *b, uint8_t picture_type, const h263mi_mb_record *d_mbs,
+                                  const uint32_t *d_block_first_event, const uint32_t *d_events, const uint64_t *d_coeff_base,
+                                  uint64_t coeff_pool_blocks, uint64_t n_events, uint8_t strength, const uint8_t *strengths,
+                                  uint8_t *d_rgba, uint8_t *d_deblocked);
 /* deblock (strength 0 = off) + BT.601 of every stream's last picture into d_rgba
  * (DEVICE, n_streams * w*h*4 bytes, stream-major); d_deblocked (DEVICE, may be NULL)
  * additionally receives the filtered planes, n_streams * (w*h + 2*cw*ch) bytes as
@@ -382,12 +415,27 @@ int h263mi_batch_submit_host_events(h263mi_batch *b, uint8_t picture_type,
  * may run on (hardware threads, affinity mask).  Under a container's quota (cgroup cpu.max of Q CPUs on a host with more):
  * the fewest threads that give the rounds of Q + Q/2 threads -- 22 for 64 streams on 16 CPUs -- and the workers PARK as soon
  * as they run out of work instead of spinning for the next call: a quota limits CPU time, not threads, and a spinning worker
- * spends it like a parsing one (h263-rs_amd/csrc/backend.cpp: HostThreadPlan; H263MI_QUOTA_OVERSUBSCRIBE=0: Q threads).  A
- * caller that passes more threads than the quota has CPUs gets the parking workers too.  Both limits are divided by
- * LOCAL_WORLD_SIZE when a launcher exports it (the ranks of a job share the node).  *cpu_quota (may be NULL) receives Q, 0 =
- * no quota.
+ * spends it like a parsing one (h263-rs_amd/csrc/worker_pool.h: HostThreadPlan; H263MI_QUOTA_OVERSUBSCRIBE=0: Q threads).  A
+ * caller that passes more threads than the quota has CPUs gets the parking workers too.  Both limits are divided by the
+ * number of processes that share the node: h263mi_set_ranks_per_node, else H263MI_RANKS_PER_NODE, else the launcher's
+ * LOCAL_WORLD_SIZE.  The host's limits are read once per process.  *cpu_quota (may be NULL) receives Q, 0 = no quota.
  */
 uint32_t h263mi_default_parser_threads(uint32_t n_streams, uint32_t *cpu_quota);
+/* (ABI 7) How many processes share this node's CPUs (and its CPU-time quota) with this one: both limits above are divided by
+ * it.  A job's launcher knows (one rank per GPU); a lone service rank started under the same launcher says 1.  0 = back to
+ * the environment: H263MI_RANKS_PER_NODE, else LOCAL_WORLD_SIZE.  Process-wide; takes effect with the next decode call and
+ * for batches made afterwards (their host threads' CPU slice, below). */
+void h263mi_set_ranks_per_node(uint32_t ranks);
+/* (ABI 7) NUMA placement of a batch's host side.  On a multi-socket node the parser threads and the pinned staging memory of
+ * a batch belong on the socket its GPU hangs off: the batch looks up the NUMA node of its device (sysfs numa_node of the PCI
+ * function), confines its host threads to that node's CPUs -- with several ranks per node: to this rank's slice of them, the
+ * node's cores dealt to the devices 0 .. ranks - 1 that hang off it in device order, so that no two ranks parse on the same
+ * cores -- and allocates its staging memory under a preferred-node policy for it.  H263MI_NUMA=0 switches it off,
+ * H263MI_NUMA_NODE=k forces node k (experiments).  This call reports what was done: the device's node (-1 = unknown / off),
+ * the node the staging memory really lies on (-1 = none yet / unknown) and the CPUs the host threads are confined to
+ * (*n_pool_cpus = how many, 0 = not confined / no threads yet; cpus, may be NULL, receives up to cpus_cap of their numbers). */
+int h263mi_batch_host_placement(const h263mi_batch *b, int *device_numa_node, int *staging_numa_node, uint32_t *n_pool_cpus,
+                                uint16_t *cpus, uint32_t cpus_cap);
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads);
 /*
@@ -411,7 +459,17 @@ int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options,
 int h263mi_batch_decode_next_pictures_ex(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                          const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
                                          uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
+/* (ABI 7) The post-filter strength per picture.  `strength` of the _ex form may be H263MI_STRENGTH_FROM_HEADER: every stream's
+ * picture is filtered with use_deblocker ? h263mi_quant_to_strength[pquant] : 0 of the header this call has just parsed for
+ * it (deblock.rs:5-8, picture.rs:61-64, types.rs:94-96, 216) -- 64 streams with 64 quantisers render drop-in, in the same
+ * launch (k_frame) as before.  The _ps form also takes the caller's own choice per stream: strengths (HOST array of n_streams
+ * values 0..12; NULL = `strength`, which may be H263MI_STRENGTH_FROM_HEADER). */
+int h263mi_batch_decode_next_pictures_ps(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
+                                         const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
+                                         uint8_t strength, const uint8_t *strengths, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_render_rgba(h263mi_batch *b, uint8_t strength, uint8_t *d_rgba, uint8_t *d_deblocked);
+/* (ABI 7) ... every stream's last picture with its own strength (strengths: HOST array of n_streams values, NULL = `strength`) */
+int h263mi_batch_render_rgba_ps(h263mi_batch *b, uint8_t strength, const uint8_t *strengths, uint8_t *d_rgba, uint8_t *d_deblocked);
 int h263mi_batch_sync(h263mi_batch *b);
 /* h263mi_batch_sync with the verdict of the device per stream: stream_rc[s] = H263MI_OK,
  * H263MI_ERR_UNCODED_IFRAME_BLOCKS or H263MI_ERR_INVALID_ARGUMENT (a coded block outside the pool).  Only the streams
@@ -481,6 +539,13 @@ int h263mi_mixed_decode_next_pictures(h263mi_mixed *m, uint32_t decoder_options,
                                       const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
                                       uint8_t strength, uint8_t *const *d_rgba, const size_t *rgba_capacity,
                                       h263mi_picture_desc *descs);
+/* (ABI 7) `strength` above may be H263MI_STRENGTH_FROM_HEADER (each picture with what its own header asks for, see
+ * h263mi_batch_decode_next_pictures_ps); the _ps form also takes one value per stream of the SET (strengths[s], 0..12; NULL =
+ * `strength`). */
+int h263mi_mixed_decode_next_pictures_ps(h263mi_mixed *m, uint32_t decoder_options, const uint8_t *const *data,
+                                         const size_t *len, size_t *consumed, uint32_t n_threads, int *stream_rc,
+                                         uint8_t strength, const uint8_t *strengths, uint8_t *const *d_rgba,
+                                         const size_t *rgba_capacity, h263mi_picture_desc *descs);
 /* waits for everything queued; stream_rc (may be NULL): the device's verdict per stream, as h263mi_batch_sync_streams */
 int h263mi_mixed_sync(h263mi_mixed *m, int *stream_rc);
 /* size of stream `stream`'s last picture (H263MI_ERR_NO_PICTURE and 0 x 0 when it has none) */

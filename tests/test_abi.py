@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "include/h263mi.h declares %s but libh263mi.so does not export it" % name
     assert declared == set(h263mi.EXPORTS), declared ^ set(h263mi.EXPORTS)
-    assert L.h263mi_abi_version() == 6
+    assert L.h263mi_abi_version() == 7
 
 
 def test_record_layout_matches_header_and_oracle():

@@ -195,13 +195,14 @@ class Workload:
         return self.n * RGBA_BYTES
 
 
-def run_frames(batch, wl, d_rgba, n_frames, pipeline=False, checked=False):
+def run_frames(batch, wl, d_rgba, n_frames, pipeline=False, checked=True):
     """n_frames frame indices starting at a GOP boundary (every GOP re-starts all streams with an I picture).
     pipeline: h263mi_batch_decode on a H263MI_CFG_PIPELINE_POST batch -- one launch per frame index reconstructs
     picture f and post-processes picture f - 1; the last picture's post-processing runs at the next sync.
-    checked: the calls say how large their arrays are (coeff_pool_blocks, n_events), as every host entry point does: the
-    waves then refuse to read a coded block outside the pool / an event list whose bounds do not ascend or reach beyond
-    the events (include/h263mi.h).  Without it the caller vouches for its arrays and the waves check nothing."""
+    checked (the default, and what the headline runs): the calls say how large their arrays are (coeff_pool_blocks,
+    n_events), as every host entry point does: the waves refuse to read a coded block outside the pool / an event list whose
+    bounds do not ascend or reach beyond the events (include/h263mi.h).  checked=False is for a batch made with
+    trusted_arrays (H263MI_CFG_TRUSTED_ARRAYS): the caller vouches, the waves check nothing (roofline.trusted_mode)."""
     g = len(wl.frames)
     for i in range(n_frames):
         fr = wl.frames[i % g]
@@ -381,6 +382,11 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
     t_enc = time.perf_counter()
     streams, recs = [], []
     uncoded = []
+    # every stream has its own picture quantiser (realistic leg: 4 .. 20) and asks for the deblocker in its header: the call
+    # renders each with H263MI_STRENGTH_FROM_HEADER = QUANT_TO_STRENGTH[its PQUANT] (deblock.rs:5-8), as a consumer of the
+    # reference would per picture (picture.rs:61-64)
+    quants = [4 + (7 * s) % 17 for s in range(n_distinct)] if realistic else [10] * n_distinct
+    q2s = [int(v) for v in h263mi.quant_to_strength()]
     for s in range(n_distinct):
         pics, rr = [], []
         for f in range(n_frames):
@@ -393,8 +399,8 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
                 uncoded.append(float(((mbs["cbp"] == 0) & ~mbs["mv"].reshape(len(mbs), -1).any(axis=1)).mean()))
             else:
                 mbs, co = h263mi.synth_picture_host(h263mi.SYNTH_P, W, H, 200 + s, f)
-            mbs = make_codable(mbs, 10, s * 100 + f, 0 if f == 0 else 1)
-            pics.append(enc.encode_picture(W, H, 0 if f == 0 else 1, 10, mbs, co, temporal_reference=f))
+            mbs = make_codable(mbs, quants[s], s * 100 + f, 0 if f == 0 else 1)
+            pics.append(enc.encode_picture(W, H, 0 if f == 0 else 1, quants[s], mbs, co, temporal_reference=f, deblock_flag=1))
             rr.append((mbs, co))
         streams.append(pics)
         recs.append(rr)
@@ -413,8 +419,8 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
 
     def run_gop(threads, sync=True):
         for f in order:
-            used, rcs = batch.decode_next_pictures_ex(None, n_threads=threads, prepared=prepared[f], strength=STRENGTH,
-                                                      d_rgba=d_rgba.ptr)
+            used, rcs = batch.decode_next_pictures_ex(None, n_threads=threads, prepared=prepared[f],
+                                                      strength=h263mi.STRENGTH_FROM_HEADER, d_rgba=d_rgba.ptr)
             if any(rcs):
                 raise RuntimeError("e2e: stream errors %s" % [r for r in rcs if r][:4])
         if sync:
@@ -443,7 +449,7 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
         for f in order:
             rc, ref = orc.decode_picture(W, H, recs[variant[s]][f][0], recs[variant[s]][f][1], ref)
         ok = ok and all(np.array_equal(g, e) for g, e in zip(batch.copy_yuv(s), ref))
-        filt = tuple(orc.deblock(p, pw, STRENGTH) for p, pw in zip(ref, (W, 960, 960)))
+        filt = tuple(orc.deblock(p, pw, q2s[quants[variant[s]]]) for p, pw in zip(ref, (W, 960, 960)))
         ok = ok and np.array_equal(d_rgba.download(RGBA_BYTES, s * RGBA_BYTES), orc.yuv420_to_rgba(*filt, W))
     # the stages on their own: the same call with one parser thread
     p_bytes = sum(len(p) for p in streams[0][1:])
@@ -460,7 +466,7 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
     pps = pics / dt
     gop_bytes = sum(len(streams[variant[s]][f]) for s in range(n) for f in order)
     p_mean = int(p_bytes / max(n_frames - 1, 1))
-    out = {"_pictures": pics, "_seconds": dt,
+    out = {"_pictures": pics, "_seconds": dt, "picture_quantisers": sorted(set(quants)),
            "pictures_per_s": round(pps, 1), "mp_per_s": round(pps * MP_PER_PICTURE, 1),
            "realtime_1080p30_streams": round(pps / 30.0, 1), "parity_vs_oracle": "ok" if ok else "MISMATCH",
            "parser_threads": cores, "gops_timed": reps, "bitstream_mb_per_s": round(gop_bytes * reps / dt / 1e6, 1),
@@ -474,11 +480,11 @@ def e2e_bitstream(h263mi, n, device_id, stream, d_rgba, n_distinct=2, n_frames=8
            "what": "%d streams x GOPs of %d pictures (1 I + %d P; %d distinct streams, the P pictures cycle through %d "
                    "encoded ones) of 1920x1080 Sorenson Spark, %s; "
                    "h263mi_batch_decode_next_pictures_ex on a frame-pipelined batch (host parser on %d threads -> events -> H2D -> "
-                   "k_frame: reconstruction from the events + deblock(%d) + BT.601 of the previous picture in one launch) per frame "
-                   "index; streams encoded by tests/sorenson_enc.py in %.1f s"
+                   "k_frame: reconstruction from the events + deblock(strength from each picture's own header: PQUANT %s) + BT.601 "
+                   "of the previous picture in one launch) per frame index; streams encoded by tests/sorenson_enc.py in %.1f s"
                    % (n, len(order), len(order) - 1, n_distinct, n_frames - 1,
                       "pictures shaped like real content" if realistic else "the bench workload's records (every macroblock coded)",
-                      cores, STRENGTH, t_enc),
+                      cores, sorted(set(quants)), t_enc),
            "limit": "host parser: the container's CPU-time quota (cpu_quota_per_rank CPUs; %d threads that park when they are "
                     "out of work share it, include/h263mi.h: h263mi_default_parser_threads); the device-resident rate of the "
                     "same kernels is the headline value" % cores}
@@ -828,34 +834,36 @@ def main(argv=None):
         roofline["valu"] = None
         roofline["bound_observed"] = None
 
-    def ms_per_frame_index(workload, n_frames, checked):
-        run_frames(batch, workload, d_rgba, args.gop, pipeline, checked)
-        batch.sync()
+    def ms_per_frame_index(bt, workload, n_frames, checked):
+        run_frames(bt, workload, d_rgba, args.gop, pipeline, checked)
+        bt.sync()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        run_frames(batch, workload, d_rgba, n_frames, pipeline, checked)
-        batch.sync()
+        run_frames(bt, workload, d_rgba, n_frames, pipeline, checked)
+        bt.sync()
         torch.cuda.synchronize()
         return (time.perf_counter() - t1) / n_frames * 1e3
 
     if not args.no_extra and pipeline:
-        # The timed region hands its arrays over WITHOUT their sizes (n_events = 0, coeff_pool_blocks = 0: "the caller
-        # vouches", include/h263mi.h) -- they are this process's own generator output.  Every host entry point, the path
-        # real streams take, passes both, and the waves then bounds-check every coded block and event list they read.  The
-        # same frames both ways, interleaved, right here:
-        pairs = [(ms_per_frame_index(wl, 2 * frames_per_step, False), ms_per_frame_index(wl, 2 * frames_per_step, True))
+        # The timed region runs CHECKED (ABI 7: the default): every call says how large its arrays are and the waves
+        # bounds-check every coded block and event list they read -- the path real streams take.  What the opt-out would buy
+        # (H263MI_CFG_TRUSTED_ARRAYS: the caller vouches, the waves check nothing): the same frames on a second batch made that
+        # way, interleaved with the checked batch, right here:
+        trusted_batch = h263mi.Batch(n, W, H, local_rank, stream, pipeline_post=True, trusted_arrays=True)
+        pairs = [(ms_per_frame_index(trusted_batch, wl, 2 * frames_per_step, False), ms_per_frame_index(batch, wl, 2 * frames_per_step, True))
                  for _ in range(2)]
+        trusted_batch.close()
         vouched = sum(p_[0] for p_ in pairs) / len(pairs)
         checked_ms = sum(p_[1] for p_ in pairs) / len(pairs)
-        roofline["checked_mode"] = {"ms_per_frame_index": round(checked_ms, 4), "vouched_ms_per_frame_index": round(vouched, 4),
-                                    "cost": round(checked_ms / vouched - 1.0, 4),
-                                    "mp_per_s": round(n * MP_PER_PICTURE / (checked_ms * 1e-3), 1),
-                                    "what": "the timed workload with coeff_pool_blocks and n_events given to "
-                                            "h263mi_batch_decode[_events] (what every host entry point does) against the headline's "
-                                            "calls, which vouch for their arrays; 2 x %d frame indices each, interleaved twice, "
-                                            "wall clock" % (2 * frames_per_step)}
+        roofline["trusted_mode"] = {"ms_per_frame_index": round(vouched, 4), "checked_ms_per_frame_index": round(checked_ms, 4),
+                                    "gain": round(checked_ms / vouched - 1.0, 4),
+                                    "mp_per_s": round(n * MP_PER_PICTURE / (vouched * 1e-3), 1),
+                                    "what": "the timed workload on a H263MI_CFG_TRUSTED_ARRAYS batch with no sizes given (the caller "
+                                            "vouches, the waves check nothing) against the headline's checked calls; 2 x %d frame "
+                                            "indices each, interleaved twice, wall clock; gain = checked / trusted - 1"
+                                            % (2 * frames_per_step)}
     else:
-        roofline["checked_mode"] = None
+        roofline["trusted_mode"] = None
 
     extra = {}
     # (the extra legs run on EVERY rank -- each on its own GPU and its own share of the host -- so that no rank sits in a
@@ -982,8 +990,8 @@ def main(argv=None):
                                "over the resident input = %d GOPs x %d frame indices = %d pictures per stream (%d per "
                                "step and GPU); GOP = 1 I (mixed block classes) + %d P (half-pel MVs in [-32,31], 25%% "
                                "coded blocks, quant 10); dequant+IDCT+MC+add/clip, deblock strength %d, BT.601 RGBA; "
-                               "records pre-generated in HBM (the calls vouch for their arrays: no pool size / event count "
-                               "given, roofline.checked_mode has the other way), coefficients %s" % (
+                               "records pre-generated in HBM (checked calls: pool size and event count given, the waves "
+                               "bounds-check what they read; roofline.trusted_mode has the opt-out), coefficients %s" % (
                                    n, args.gops_per_step, args.gop, frames_per_step, n * frames_per_step, args.gop - 1, STRENGTH,
                                    "as sparse events (one 32-bit word per non-zero LEVEL: the host parser's transport form, "
                                    "h263mi_batch_decode_events) for the P pictures, dense blocks for the GOP's I picture" if use_events else "as dense int16[64] blocks (h263mi_batch_decode)"),

@@ -214,14 +214,15 @@ def lib():
                                                 C.POINTER(sz)]
         L.h263mi_synth_batch_device_strided.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, u32, vp, vp, sz, vp,
                                                         C.POINTER(sz)]
-        L.h263mi_batch_decode_ps.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp, vp]
-        L.h263mi_batch_decode_events_ps.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8, vp, vp, vp]
-        L.h263mi_batch_render_rgba_ps.argtypes = [vp, u8, vp, vp, vp]
-        L.h263mi_batch_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp]
-        L.h263mi_mixed_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp, vp]
-        L.h263mi_set_ranks_per_node.argtypes = [u32]
-        L.h263mi_set_ranks_per_node.restype = None
-        L.h263mi_batch_host_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), vp, u32]
+        if hasattr(L, "h263mi_batch_decode_ps"):         # (ABI 7; a library of an earlier round -- tools/ab_inproc.py -- lacks them)
+            L.h263mi_batch_decode_ps.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp, vp]
+            L.h263mi_batch_decode_events_ps.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8, vp, vp, vp]
+            L.h263mi_batch_render_rgba_ps.argtypes = [vp, u8, vp, vp, vp]
+            L.h263mi_batch_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp]
+            L.h263mi_mixed_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp, vp]
+            L.h263mi_set_ranks_per_node.argtypes = [u32]
+            L.h263mi_set_ranks_per_node.restype = None
+            L.h263mi_batch_host_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), vp, u32]
         L.h263mi_default_parser_threads.restype = u32
         L.h263mi_default_parser_threads.argtypes = [u32, C.POINTER(u32)]
         _lib = L
@@ -521,6 +522,10 @@ class Batch:
                d_deblocked=None, strengths=None):
         """submit + render_rgba in one call (h263mi_batch_decode[_ps]).  strengths: one value per stream (ABI 7)"""
         keep, ps = self._strengths(strengths)
+        if ps is None and not hasattr(lib(), "h263mi_batch_decode_ps"):          # (a library of an earlier round: A/B runs)
+            _check(lib().h263mi_batch_decode(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength,
+                                             d_rgba, d_deblocked), "batch_decode")
+            return
         _check(lib().h263mi_batch_decode_ps(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength, ps,
                                             d_rgba, d_deblocked), "batch_decode")
 
@@ -531,6 +536,10 @@ class Batch:
         read and its picture is rejected.  0 = not told: the library bounds the arrays by the allocations they lie in (ABI 7)
         -- unless the batch was made with trusted_arrays, where 0 means the caller vouches and nothing is checked."""
         keep, ps = self._strengths(strengths)
+        if ps is None and not hasattr(lib(), "h263mi_batch_decode_events_ps"):
+            _check(lib().h263mi_batch_decode_events(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
+                                                    coeff_pool_blocks, n_events, strength, d_rgba, d_deblocked), "batch_decode_events")
+            return
         _check(lib().h263mi_batch_decode_events_ps(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
                                                    coeff_pool_blocks, n_events, strength, ps, d_rgba, d_deblocked), "batch_decode_events")
 

@@ -6,6 +6,7 @@ incl. the Sorenson 7- and 11-bit escapes (block.rs:1707-2124).  Data: tests/gold
 import json
 import os
 
+import numpy as np
 import pytest
 
 import parselib as pl
@@ -140,3 +141,57 @@ def test_mv_prediction_and_sorenson_header_known_answers_derived_from_the_refere
             assert mbs[k]["mv"].tolist() == e["mv"], "%s, macroblock %d: got %s, the reference text gives %s (%s)" % (
                 pic["name"], k, mbs[k]["mv"].tolist(), e["mv"], mb["derivation"])
             assert int(mbs[k]["cbp"]) == 0 and int(mbs[k]["quant"]) == pic["quant"]
+
+
+def _content_fixture():
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "macroblock_content_known_answers.json")))
+
+
+def fixture_picture_bytes(pic):
+    """the literal bit strings of a fixture picture, concatenated and zero-padded to a byte boundary -- nothing else"""
+    bits = "".join(pic["header_bits"]) + "".join("".join(mb["bits"]) for mb in pic["macroblocks"])
+    assert set(bits) <= {"0", "1"}
+    bits += "0" * (-len(bits) % 8)
+    return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+
+def test_macroblocks_with_content_known_answers_derived_from_the_reference_text():
+    """tests/golden/macroblock_content_known_answers.json: hand-derived bit strings that carry
+    CONTENT behind the macroblock header -- non-zero CBPY in both senses (the inversion of macroblock.rs:479-489), every
+    MCBPC chroma pattern, DQUANT with the clamp of state.rs:226-227 at both ends, four-vector candidates (mvd_pred.rs:27-67),
+    TCOEF events incl. LAST, the 7-, 11- and 8-bit escapes (block.rs:694-708), a run that overflows (rle.rs:125-127),
+    stuffing, a picture that ends with its data in the middle of a row (state.rs:411, 421-427).  The parser's records, kill
+    flags and coefficient blocks must be what the reference's text gives.  tests/sorenson_enc.py is not involved."""
+    gold = _content_fixture()
+    for pic in gold["pictures"]:
+        data = fixture_picture_bytes(pic)
+        pl.context_reset()
+        rc, d, mbs, co, used = pl.parse_picture(data, options=1)
+        assert rc == 0, pic["name"]
+        assert (d.width, d.height, d.picture_type, d.pquant, d.temporal_reference, d.use_deblocker) == (
+            pic["width"], pic["height"], pic["picture_type"], pic["quant"], pic["temporal_reference"], pic["use_deblocker"])
+        assert len(mbs) == pic["n_records"] == len(pic["macroblocks"]), (pic["name"], len(mbs))
+        at = 0
+        for k, mb in enumerate(pic["macroblocks"]):
+            e, r, what = mb["expect"], mbs[k], "%s, macroblock %d (%s)" % (pic["name"], k, mb["derivation"])
+            assert int(r["mb_type"]) == e["mb_type"], what
+            assert int(r["cbp"]) == e["cbp"], what
+            assert int(r["kill"]) == e["kill"], what
+            assert r["mv"].tolist() == e["mv"], what
+            if "quant" in e:
+                assert int(r["quant"]) == e["quant"], what
+            if "intradc" in e:
+                assert r["intradc"].tolist() == e["intradc"], what
+            intra = e["mb_type"] in (3, 4)
+            assert len(e["blocks"]) == bin(e["cbp"]).count("1"), what
+            if e["blocks"]:
+                assert int(r["coeff_index"]) == at, what
+            for j, blk in enumerate(e["blocks"]):
+                got = co[at + j]
+                if blk is not None:                              # (null: a killed block, its coefficients do not count)
+                    have = {int(p): int(got[p]) for p in np.flatnonzero(got) if not (intra and p == 0)}
+                    assert have == {int(p): v for p, v in blk.items()}, "%s: block %d: %s" % (what, j, have)
+            at += len(e["blocks"])
+        assert len(co) == at
+        # the windowed fast paths and the field-by-field transcription agree on these bytes too
+        assert pl.compare_parser_paths(data)[0] == 0, pic["name"]

@@ -253,6 +253,8 @@ int h263mi_batch::submit(uint8_t picture_type, const MbRecord *d_mbs, const h263
     const bool all_same = uniform() && (!with_post || (pending_uniform() && pending.set[0] >= 0 && !pending.rgba_ptrs &&
                                                        pending.strength.same_for_all()));
     int out0 = 0;
+    std::vector<uint32_t> words;                 // one STREAM_* word per stream when they differ (empty: they do not)
+    const bool words_inline = n <= STREAM_WORDS_INLINE;       // ... which then travel in the launch's kernel arguments
     if (all_same) {
         const int cur = ss[0].cur;
         out0 = cur < 0 ? 0 : (cur ^ 1);
@@ -262,7 +264,7 @@ int h263mi_batch::submit(uint8_t picture_type, const MbRecord *d_mbs, const h263
         a.has_ref = (ss[0].has_ref && cur >= 0) ? 1u : 0u;
         if (with_post) pa.frames = frames[pending.set[0]];
     } else {
-        std::vector<uint32_t> words(n);
+        words.resize(n);
         for (uint32_t i = 0; i < n; i++) {
             const StreamState &t = ss[i];
             uint32_t w = (t.cur != 0 ? STREAM_REF_SET1 : 0u) | ((t.has_ref && t.cur >= 0) ? STREAM_HAS_REF : 0u) |
@@ -271,10 +273,11 @@ int h263mi_batch::submit(uint8_t picture_type, const MbRecord *d_mbs, const h263
             else w |= (pending.set[i] == 1 ? STREAM_POST_SET1 : 0u) | ((uint32_t)pending.strength.of(i) << STREAM_STRENGTH_SHIFT);
             words[i] = w;
         }
+        // (a batch of more than STREAM_WORDS_INLINE streams: the words go to device memory, a small copy in front of the launch)
         const uint32_t *d_words = nullptr;
-        RC_TRY(push_stream_words(words, &d_words, stream));
+        if (!words_inline) RC_TRY(push_stream_words(words, &d_words, stream));
         a.stream_state = d_words;
-        a.ref = frames[0];                   // (never used with stream_state; never null)
+        a.ref = frames[0];                   // (never used with per-stream words; never null)
         a.cur = frames[1];
         if (with_post) {
             pa.stream_state = d_words;
@@ -290,7 +293,7 @@ int h263mi_batch::submit(uint8_t picture_type, const MbRecord *d_mbs, const h263
     }
     if (with_post) {
         RC_TRY(time_begin(2));
-        const hipError_t e = launch_frame(a, pa, stream, (frame_launches++ & 1u) != 0);
+        const hipError_t e = launch_frame(a, pa, stream, (frame_launches++ & 1u) != 0, !words.empty() && words_inline ? words.data() : nullptr);
         if (e != hipSuccess) {               // the deferred post-processing must not get lost with the failed launch
             (void)flush_pending();
             return map_hip_error(e);
@@ -298,7 +301,7 @@ int h263mi_batch::submit(uint8_t picture_type, const MbRecord *d_mbs, const h263
         pending.valid = false;
     } else {
         RC_TRY(time_begin(0));
-        HIP_TRY(launch_recon(a, stream));
+        HIP_TRY(launch_recon(a, stream, !words.empty() && words_inline ? words.data() : nullptr));
     }
     if (overlap_post) HIP_TRY(hipEventRecord(ev_recon_done, stream));
     // reference bookkeeping, state.rs:464-483, per stream
@@ -339,19 +342,21 @@ int h263mi_batch::launch_post_sets(const std::vector<int8_t> &sets, const Streng
     if (!any) return H263MI_OK;
     PostArgs a = post_args(sets[0] >= 0 ? sets[0] : 0, strength.of(0), d_rgba, d_planes);
     a.rgba_ptrs = rgba_ptrs;
+    std::vector<uint32_t> words;
+    const bool words_inline = n <= STREAM_WORDS_INLINE;
     if (!same) {
-        std::vector<uint32_t> words(n);
+        words.resize(n);
         for (uint32_t i = 0; i < n; i++)
             words[i] = STREAM_RECON_SKIP | (sets[i] < 0 ? STREAM_POST_SKIP : (sets[i] == 1 ? STREAM_POST_SET1 : 0u)) |
                        ((uint32_t)strength.of(i) << STREAM_STRENGTH_SHIFT);
         const uint32_t *d_words = nullptr;
-        RC_TRY(push_stream_words(words, &d_words, on));
+        if (!words_inline) RC_TRY(push_stream_words(words, &d_words, on));
         a.stream_state = d_words;
         a.frame_set[0] = frames[0];
         a.frame_set[1] = frames[1];
     }
     RC_TRY(time_begin(1));
-    HIP_TRY(launch_post(a, on));
+    HIP_TRY(launch_post(a, on, !words.empty() && words_inline ? words.data() : nullptr));
     return H263MI_OK;
 }
 

@@ -115,6 +115,15 @@ enum : uint32_t {
     STREAM_STRENGTH_MASK = 15u,
 };
 
+// A launch of up to STREAM_WORDS_INLINE pictures carries the streams' words IN ITS KERNEL ARGUMENTS (round 6): nothing is
+// copied to the device in front of the launch -- the small H2D copy between two launches cost the 64-stream loop 2 % (5 us
+// of bubble per frame index, tools/probes/strength_ab.py) -- and a wave reads its picture's word with one scalar load from
+// the kernarg segment.  Larger launches read them from a device array (ReconArgs / PostArgs::stream_state).
+constexpr uint32_t STREAM_WORDS_INLINE = 64;
+struct StreamWords {
+    uint32_t w[STREAM_WORDS_INLINE];
+};
+
 // ---------------------------------------------------------------------------
 // reconstruction kernel arguments
 // ---------------------------------------------------------------------------
@@ -128,7 +137,8 @@ struct ReconArgs {
     const uint8_t *ref;          // reference frames (picture p at + p*frame_bytes); never null
     uint8_t *cur;                // output frames
     uint32_t *status;            // device status words, one per picture (stream)
-    const uint32_t *stream_state;// per-stream STREAM_* words, or nullptr: every stream reads `ref`, writes `cur`, has `has_ref`
+    const uint32_t *stream_state;// per-stream STREAM_* words (device array), or nullptr: with words_inline 0 too, every stream
+                                 // reads `ref`, writes `cur`, has `has_ref`
     uint8_t *frame_set[2];       // the two frame sets (used with stream_state)
     uint64_t coeff_pool_blocks;  // size of the pool (blocks), used when coeff_checked is set
     uint32_t coeff_checked;      // 1: a coded block whose index is >= coeff_pool_blocks is an error (and is not read)
@@ -148,7 +158,7 @@ struct ReconArgs {
     const uint32_t *mb_group_index;
     const uint64_t *mb_base;
     uint32_t groups_per_picture;
-    uint32_t pad_;
+    uint32_t words_inline;       // 1: the per-stream words are the launch's StreamWords argument (set by the launcher), not stream_state
 };
 
 // ---------------------------------------------------------------------------
@@ -167,7 +177,7 @@ struct PostArgs {
     uint32_t luma_only;          // standalone deblock() of a single plane
     uint32_t inv_tiles_x;        // ceil(2^32 / tiles_x) (set by the launcher)
     uint32_t wrap;               // 1: tile column 0 does not exist, its 4 picture columns ride in the last tile (post_kernel.inl)
-    uint32_t pad;
+    uint32_t words_inline;       // 1: the per-stream words are the launch's StreamWords argument (set by the launcher)
     uint8_t *const *rgba_ptrs;   // with stream_state only (or nullptr): picture p's RGBA goes to rgba_ptrs[p] instead of
                                  // rgba + p * w*h*4 -- streams whose outputs are separate buffers (a batch of mixed sizes)
 };

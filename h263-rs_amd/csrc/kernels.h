@@ -27,12 +27,15 @@ struct FrameGeom {
     uint32_t flip;              // walk the pictures of the batch in descending order
     uint32_t bands;             // XCDs that share one picture (8, 4 or 2): 8 / bands pictures side by side
 };
-hipError_t launch_recon(const ReconArgs &args, hipStream_t stream);
+// `words` (HOST pointer, n_pictures STREAM_* words, or nullptr): the streams of the launch differ -- each picture's waves read
+// its word.  Up to STREAM_WORDS_INLINE pictures they travel in the kernel arguments; beyond that the caller has put them into
+// device memory (args.stream_state) and passes nullptr here.
+hipError_t launch_recon(const ReconArgs &args, hipStream_t stream, const uint32_t *words = nullptr);
 // k_recon over `rargs` and k_post over `pargs` (same number of pictures, same picture size) as ONE launch.
 // `descending`: walk the pictures last to first.  A caller that alternates the direction from one frame index to the
 // next reads the planes it wrote last -- the ones still in the infinity cache -- first (2 % on a 64-stream batch).
-hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream, bool descending);
-hipError_t launch_post(const PostArgs &args, hipStream_t stream);
+hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream, bool descending, const uint32_t *words = nullptr);
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, const uint32_t *words = nullptr);
 hipError_t launch_synth_headers(const SynthArgs &args, hipStream_t stream);
 hipError_t launch_synth_coeffs(const SynthArgs &args, hipStream_t stream);
 // streaming probes: mode 0 copy in -> out, 1 read in (out = 16-byte sink), 2 write out; bytes is a multiple of 16;

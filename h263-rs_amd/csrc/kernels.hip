@@ -298,7 +298,8 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
 }
 
 // One wave's share of the reconstruction: the 8 macroblocks at `p`.
-__device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan)
+__device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan,
+                                           const StreamWords &sw)
 {
     if (p.mby >= (int)a0.L.mbh) return;
 #if H263MI_STOP_RECON == 9
@@ -307,8 +308,8 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     // A batch whose streams have drifted apart (dev_common.h: STREAM_*) says per stream where its reference lives, whether
     // it has one, and whether it takes part in this call at all (uniform: one scalar load per wave).
     ReconArgs a = a0;
-    if (a0.stream_state) {
-        const uint32_t st = a0.stream_state[p.pic];
+    if (a0.stream_state || a0.words_inline) {
+        const uint32_t st = a0.words_inline ? sw.w[p.pic] : a0.stream_state[p.pic];      // (from the kernel arguments, or device memory)
         if (st & STREAM_RECON_SKIP) return;
         const uint32_t set = st & STREAM_REF_SET1;
         a.ref = a0.frame_set[set];
@@ -367,7 +368,7 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     PHASE_MARK(6);
 }
 
-__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
+__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a, StreamWords sw)
 {
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a)
     p.cbase = 0;
     PrefetchPlan plan = {p, p};
     plan.far.pic = plan.near.pic = -1;              // (no prefetch in the stand-alone kernel)
-    recon_wave(a, waves[wave], lane, p, plan);
+    recon_wave(a, waves[wave], lane, p, plan, sw);
 }
 
 // Bands per picture: the XCDs that share one picture's work list (k_recon, k_frame).  Measured on the 64-stream bench
@@ -413,17 +414,28 @@ static uint32_t frame_bands(uint32_t n_pictures) { return n_pictures >= 16 ? H26
 // ceil(2^32 / d): n / d == mul_hi(n, r) for n * d < 2^32
 static uint32_t reciprocal_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
 
-hipError_t launch_recon(const ReconArgs &args, hipStream_t stream)
+// the streams' words of a launch -> its StreamWords argument; false (and nothing set) when there are none or too many pictures
+static bool inline_words(const uint32_t *words, uint32_t n_pictures, StreamWords &sw)
+{
+    if (!words || n_pictures > STREAM_WORDS_INLINE) return false;
+    for (uint32_t i = 0; i < STREAM_WORDS_INLINE; i++) sw.w[i] = i < n_pictures ? words[i] : 0u;
+    return true;
+}
+
+hipError_t launch_recon(const ReconArgs &args, hipStream_t stream, const uint32_t *words)
 {
     if (!args.n_pictures) return hipSuccess;
     if (args.n_pictures > 65535 || args.tiles_x * args.tiles_y >= (1u << 20)) return hipErrorInvalidValue;
+    if (words && args.n_pictures > STREAM_WORDS_INLINE) return hipErrorInvalidValue;      // (the caller's job: device words)
     ReconArgs a = args;
+    StreamWords sw{};
+    a.words_inline = inline_words(words, args.n_pictures, sw) ? 1u : 0u;
     a.inv_tiles_x = reciprocal_u32(args.tiles_x);
     const uint32_t upp = args.tiles_x * args.tiles_y * (TILE_WAVES / RECON_WAVES);
     a.bands = frame_bands(args.n_pictures);
     const uint32_t chunk = (upp + a.bands - 1) / a.bands, side_by_side = 8 / a.bands;
     hipLaunchKernelGGL(k_recon, dim3(chunk * 8, (args.n_pictures + side_by_side - 1) / side_by_side), dim3(RECON_THREADS), 0,
-                       stream, a);
+                       stream, a, sw);
     return hipGetLastError();
 }
 
@@ -504,15 +516,15 @@ __device__ __forceinline__ void post_tile(const PostArgs &a, PostStrip &s, int l
 }
 
 template <bool STREAM_RGBA>
-__device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int lane, int sx, int ty, int pic)
+__device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int lane, int sx, int ty, int pic, const StreamWords &sw)
 {
     if (ty >= (int)a0.tiles_y) return;
 #if H263MI_STOP_POST == 9
     return;                                         // (counting build: the wave does nothing at all)
 #endif
     PostArgs a = a0;
-    if (a0.stream_state) {                          // streams that have drifted apart (dev_common.h: STREAM_*): uniform
-        const uint32_t st = a0.stream_state[pic];
+    if (a0.stream_state || a0.words_inline) {       // streams that differ (dev_common.h: STREAM_*): uniform
+        const uint32_t st = a0.words_inline ? sw.w[pic] : a0.stream_state[pic];
         if (st & STREAM_POST_SKIP) return;
         a.frames = a0.frame_set[(st & STREAM_POST_SET1) ? 1 : 0];
         a.strength = (st >> STREAM_STRENGTH_SHIFT) & STREAM_STRENGTH_MASK;      // this picture's own (deblock.rs:5-8)
@@ -524,7 +536,7 @@ __device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int 
     else post_tile<STREAM_RGBA, false>(a, s, lane, sx, ty, pic);
 }
 
-__global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
+__global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a, StreamWords sw)
 {
     __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
     const int pic = (int)blockIdx.y;
     const uint32_t gy = div_tiles_x(wg, a.tiles_x, a.inv_tiles_x);
     const int sx = (int)(wg - gy * a.tiles_x + a.wrap), ty = (int)gy * POST_GROUP + gw;      // (wrap: the first tile column is 1)
-    post_wave<false>(a, strips[wave], lane, sx, ty, pic);
+    post_wave<false>(a, strips[wave], lane, sx, ty, pic, sw);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a)
 // at the same time on the same XCD: the planes are fetched from HBM once per frame instead of twice, and waves
 // bound by arithmetic and address work (reconstruction) share every CU with waves bound by stores (RGBA).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg)
+__global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg, StreamWords sw)
 {
 #if defined(H263MI_LDS_PAD)
     // experiment: what a larger LDS footprint per wave (fewer resident waves) costs
@@ -610,21 +622,22 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
                 q.mby = (int)group3 * TILE_MBY + (int)(r3 & 1);
             }
         }
-        recon_wave(ra, lds.r, lane, p, plan);
+        recon_wave(ra, lds.r, lane, p, plan, sw);
     } else {
         if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
 #if defined(H263MI_EXP_PLAIN_RGBA)
-        post_wave<false>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic);
+        post_wave<false>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic, sw);
 #else
-        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic);
+        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic, sw);
 #endif
     }
 }
 
-hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream, bool descending)
+hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream_t stream, bool descending, const uint32_t *words)
 {
     if (!rargs.n_pictures) return hipSuccess;
     if (rargs.n_pictures != pargs.n_pictures || rargs.n_pictures > 65535) return hipErrorInvalidValue;
+    if (words && rargs.n_pictures > STREAM_WORDS_INLINE) return hipErrorInvalidValue;
     static_assert(RECON_WAVES == 1 && TILE_WAVES == 2 && POST_WAVES == 1, "k_frame is written for single-wave workgroups");
     FrameGeom fg;
     fg.recon_per_group = rargs.tiles_x * TILE_WAVES;
@@ -639,21 +652,26 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
     PostArgs pa = pargs;
     ra.inv_tiles_x = reciprocal_u32(rargs.tiles_x);
     pa.inv_tiles_x = reciprocal_u32(pargs.tiles_x);
+    StreamWords sw{};
+    ra.words_inline = pa.words_inline = inline_words(words, rargs.n_pictures, sw) ? 1u : 0u;
     const uint32_t chunk = (fg.groups * per_group + fg.bands - 1) / fg.bands, side_by_side = 8 / fg.bands;
     hipLaunchKernelGGL(k_frame, dim3(chunk * 8, (rargs.n_pictures + side_by_side - 1) / side_by_side), dim3(64), 0, stream, ra,
-                       pa, fg);
+                       pa, fg, sw);
     return hipGetLastError();
 }
 
-hipError_t launch_post(const PostArgs &args, hipStream_t stream)
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, const uint32_t *words)
 {
     if (!args.n_pictures) return hipSuccess;
     if (args.n_pictures > 65535 || args.tiles_x * args.tiles_y >= (1u << 20)) return hipErrorInvalidValue;
+    if (words && args.n_pictures > STREAM_WORDS_INLINE) return hipErrorInvalidValue;
     PostArgs a = args;
+    StreamWords sw{};
+    a.words_inline = inline_words(words, args.n_pictures, sw) ? 1u : 0u;
     a.inv_tiles_x = reciprocal_u32(args.tiles_x);
     const uint32_t groups_y = (args.tiles_y + POST_GROUP - 1) / POST_GROUP;
     const uint32_t upp = args.tiles_x * groups_y * (POST_GROUP / POST_WAVES), chunk = (upp + 7) / 8;
-    hipLaunchKernelGGL(k_post, dim3(chunk * 8, args.n_pictures), dim3(POST_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_post, dim3(chunk * 8, args.n_pictures), dim3(POST_THREADS), 0, stream, a, sw);
     return hipGetLastError();
 }
 

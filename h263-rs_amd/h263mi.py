@@ -132,6 +132,20 @@ def build(force=False):
 _lib = None
 
 
+class _MissingExport:
+    argtypes = restype = None
+
+    def __init__(self, name):
+        self.name = name
+
+    def __call__(self, *a):
+        raise RuntimeError("%s: this build of libh263mi.so does not export %s" % (LIB_PATH, self.name))
+
+
+def _has(name):
+    return not isinstance(getattr(lib(), name, None), _MissingExport)
+
+
 def lib():
     """Load the C-ABI library; fails loudly if it has not been built."""
     global _lib
@@ -140,6 +154,13 @@ def lib():
             raise RuntimeError("libh263mi.so is missing: run `make -C h263-rs_amd` (hipcc, gfx950). "
                                "There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        # A library of an EARLIER round (tools/ab_inproc.py runs them beside HEAD) lacks the newer exports: a stand-in takes
+        # the signature assignments below and raises when called.  (tests/test_abi.py holds HEAD's library to every export.)
+        for name in EXPORTS:
+            try:
+                getattr(L, name)
+            except AttributeError:
+                setattr(L, name, _MissingExport(name))
         vp, sz, u8, u16, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint16, C.c_uint32, C.c_int
         L.h263mi_strerror.restype = C.c_char_p
         L.h263mi_strerror.argtypes = [i32]
@@ -214,15 +235,14 @@ def lib():
                                                 C.POINTER(sz)]
         L.h263mi_synth_batch_device_strided.argtypes = [C.POINTER(BackendCfg), i32, u16, u16, u32, u32, u32, u32, vp, vp, sz, vp,
                                                         C.POINTER(sz)]
-        if hasattr(L, "h263mi_batch_decode_ps"):         # (ABI 7; a library of an earlier round -- tools/ab_inproc.py -- lacks them)
-            L.h263mi_batch_decode_ps.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp, vp]
-            L.h263mi_batch_decode_events_ps.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8, vp, vp, vp]
-            L.h263mi_batch_render_rgba_ps.argtypes = [vp, u8, vp, vp, vp]
-            L.h263mi_batch_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp]
-            L.h263mi_mixed_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp, vp]
-            L.h263mi_set_ranks_per_node.argtypes = [u32]
-            L.h263mi_set_ranks_per_node.restype = None
-            L.h263mi_batch_host_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), vp, u32]
+        L.h263mi_batch_decode_ps.argtypes = [vp, u8, vp, vp, vp, C.c_uint64, u8, vp, vp, vp]
+        L.h263mi_batch_decode_events_ps.argtypes = [vp, u8, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8, vp, vp, vp]
+        L.h263mi_batch_render_rgba_ps.argtypes = [vp, u8, vp, vp, vp]
+        L.h263mi_batch_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp]
+        L.h263mi_mixed_decode_next_pictures_ps.argtypes = [vp, u32, vp, vp, vp, u32, vp, u8, vp, vp, vp, vp]
+        L.h263mi_set_ranks_per_node.argtypes = [u32]
+        L.h263mi_set_ranks_per_node.restype = None
+        L.h263mi_batch_host_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), vp, u32]
         L.h263mi_default_parser_threads.restype = u32
         L.h263mi_default_parser_threads.argtypes = [u32, C.POINTER(u32)]
         _lib = L
@@ -522,7 +542,7 @@ class Batch:
                d_deblocked=None, strengths=None):
         """submit + render_rgba in one call (h263mi_batch_decode[_ps]).  strengths: one value per stream (ABI 7)"""
         keep, ps = self._strengths(strengths)
-        if ps is None and not hasattr(lib(), "h263mi_batch_decode_ps"):          # (a library of an earlier round: A/B runs)
+        if ps is None and not _has("h263mi_batch_decode_ps"):          # (a library of an earlier round: A/B runs)
             _check(lib().h263mi_batch_decode(self._h, picture_type, d_mbs, d_coeffs, d_coeff_base, coeff_pool_blocks, strength,
                                              d_rgba, d_deblocked), "batch_decode")
             return
@@ -536,7 +556,7 @@ class Batch:
         read and its picture is rejected.  0 = not told: the library bounds the arrays by the allocations they lie in (ABI 7)
         -- unless the batch was made with trusted_arrays, where 0 means the caller vouches and nothing is checked."""
         keep, ps = self._strengths(strengths)
-        if ps is None and not hasattr(lib(), "h263mi_batch_decode_events_ps"):
+        if ps is None and not _has("h263mi_batch_decode_events_ps"):
             _check(lib().h263mi_batch_decode_events(self._h, picture_type, d_mbs, d_block_first_event, d_events, d_coeff_base,
                                                     coeff_pool_blocks, n_events, strength, d_rgba, d_deblocked), "batch_decode_events")
             return
@@ -784,6 +804,10 @@ def synth_batch_device(kind, width, height, n_streams, first_stream_id, frame_id
     """picture p of the batch is stream first_stream_id + p * stream_stride"""
     cfg = BackendCfg(device_id, 0, stream)
     total = C.c_size_t(0)
+    if stream_stride == 1 and not _has("h263mi_synth_batch_device_strided"):
+        _check(lib().h263mi_synth_batch_device(C.byref(cfg), kind, width, height, n_streams, first_stream_id, frame_idx, d_mbs,
+                                               d_coeffs, capacity_blocks, d_coeff_base, C.byref(total)), "synth_batch_device")
+        return total.value
     _check(lib().h263mi_synth_batch_device_strided(C.byref(cfg), kind, width, height, n_streams, first_stream_id, stream_stride,
                                                    frame_idx, d_mbs, d_coeffs, capacity_blocks, d_coeff_base, C.byref(total)),
            "synth_batch_device")

@@ -1,0 +1,178 @@
+// tests/tsan/tsan_driver.cpp -- the host pipeline of libh263mi under ThreadSanitizer.
+//
+// Built with g++ -fsanitize=thread from the PRODUCT's host sources (worker_pool.cpp, batch.cpp, batch_staging.cpp,
+// mixed_set.cpp, state.cpp, device_util.cpp, host/bitstream.cpp) against a stub of the HIP runtime (hip_stub/, plain malloc
+// for device and pinned memory, stub kernel launchers): what runs here is the real WorkerPool (spin-then-park, generation
+// word), the real stream-affinity / stealing deal, the real parser writing records, events, block offsets and the group index
+// of N streams straight into one pinned staging slot at per-stream pitches, and the real enqueue path that reads the slot.
+// The reference needs none of this: it is single-threaded safe Rust (`&mut self`, state.rs:138-141).
+//
+// Scenarios (all through the C ABI):
+//   * one batch, calls back to back with 1 .. 40 parser threads, random NULL streams, random pauses between the calls so that
+//     the workers are met spinning, about to park and parked; under a fake 2-CPU quota (H263MI_CGROUP_CPU_MAX) so that calls
+//     with more threads than the quota take the parking plan (spin 0) and the others the spinning plan;
+//   * pools torn down in the middle of an idle spin and right after a call;
+//   * two batches and a mixed-size set driven from three threads at the same time (distinct objects may be);
+//   * the packed (H263MI_DIRECT_WORDS=0) transport, and workers that never park (H263MI_SPIN_US = 50 ms, no quota, at most 6
+//     threads: every hand-over goes through the generation word alone, never through the mutex): further runs of the test.
+// Exit code 0 and no ThreadSanitizer report = pass.  The same driver built with -DH263MI_TSAN_BREAK_GENERATION_ORDER (the task is
+// published with a relaxed store: worker_pool.cpp) MUST make ThreadSanitizer report a race: tests/test_tsan.py checks both.
+// usage: tsan_driver <corpus.bin> [rounds [max threads]]      corpus: u32 streams, u32 frames, then per (stream, frame): u32 length, bytes
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../include/h263mi.h"
+
+static std::vector<std::vector<std::vector<uint8_t>>> g_corpus;      // [stream][frame]
+static uint16_t g_w, g_h;
+static std::atomic<int> g_failures{0};
+static uint32_t g_max_threads = 40;                                  // (third argument: runs whose workers SPIN keep within the CPUs)
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            fprintf(stderr, "tsan_driver: %s:%d: %s failed\n", __FILE__, __LINE__, #cond); \
+            g_failures.fetch_add(1);                                                 \
+        }                                                                            \
+    } while (0)
+
+static bool load_corpus(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    uint32_t hdr[4];
+    if (fread(hdr, 4, 4, f) != 4) return false;
+    g_w = (uint16_t)hdr[2];
+    g_h = (uint16_t)hdr[3];
+    g_corpus.assign(hdr[0], std::vector<std::vector<uint8_t>>(hdr[1]));
+    for (auto &s : g_corpus)
+        for (auto &p : s) {
+            uint32_t n = 0;
+            if (fread(&n, 4, 1, f) != 1) return false;
+            p.resize(n);
+            if (n && fread(p.data(), 1, n, f) != n) return false;
+        }
+    fclose(f);
+    return true;
+}
+
+// one batch of `n` streams: every call decodes the next picture of a random subset of them
+static void drive_batch(unsigned seed, uint32_t n, int calls, bool pipeline, bool destroy_mid_spin)
+{
+    std::mt19937 rng(seed);
+    h263mi_backend_cfg cfg{0, pipeline ? H263MI_CFG_PIPELINE_POST : 0u, nullptr};
+    h263mi_batch *b = nullptr;
+    CHECK(h263mi_batch_create(n, g_w, g_h, &cfg, &b) == H263MI_OK);
+    if (!b) return;
+    void *d_rgba = nullptr;
+    CHECK(h263mi_device_malloc(0, (size_t)n * g_w * g_h * 4, &d_rgba) == H263MI_OK);
+    std::vector<uint32_t> next(n, 0);
+    const uint32_t frames = (uint32_t)g_corpus[0].size();
+    static const uint32_t kThreads[] = {1, 2, 3, 5, 8, 13, 16, 24, 40};
+    for (int c = 0; c < calls; c++) {
+        std::vector<const uint8_t *> data(n, nullptr);
+        std::vector<size_t> len(n, 0), used(n, 0);
+        std::vector<int> rcs(n, 0);
+        uint32_t with_data = 0;
+        for (uint32_t s = 0; s < n; s++) {
+            const bool key = next[s] == 0;
+            if (!key && rng() % 4 == 0) continue;                          // no picture for this stream in this call
+            if (next[s] >= frames) next[s] = 0;                            // (the corpus starts every stream with a key frame)
+            const std::vector<uint8_t> &p = g_corpus[s % g_corpus.size()][next[s]];
+            data[s] = p.data();
+            len[s] = p.size();
+            with_data++;
+        }
+        uint32_t threads = kThreads[rng() % (sizeof kThreads / sizeof kThreads[0])];
+        if (threads > g_max_threads) threads = 1 + threads % g_max_threads;
+        const int rc = h263mi_batch_decode_next_pictures_ex(b, H263MI_SORENSON_SPARK_BITSTREAM, data.data(), len.data(), used.data(),
+                                                            threads, rcs.data(), H263MI_STRENGTH_FROM_HEADER, (uint8_t *)d_rgba, nullptr);
+        CHECK(rc == H263MI_OK);
+        for (uint32_t s = 0; s < n; s++) {
+            if (!data[s]) continue;
+            CHECK(rcs[s] == H263MI_OK);
+            CHECK(used[s] == len[s] || used[s] + 1 == len[s]);      // (whole bytes: the last one may be half padding)
+            if (rcs[s] == H263MI_OK) next[s]++;
+        }
+        if (c % 7 == 6) CHECK(h263mi_batch_sync(b) == H263MI_OK);
+        // pauses of 0 .. 700 us: shorter, about as long and longer than the workers' 300 us spin
+        const unsigned pause = rng() % 8;
+        if (pause) std::this_thread::sleep_for(std::chrono::microseconds(100 * pause));
+    }
+    if (!destroy_mid_spin) std::this_thread::sleep_for(std::chrono::milliseconds(2));     // everybody parked
+    CHECK(h263mi_batch_sync(b) == H263MI_OK);
+    h263mi_batch_destroy(b);                                               // (pool teardown: mid-spin or parked)
+    CHECK(h263mi_device_free(0, d_rgba) == H263MI_OK);
+}
+
+static void drive_mixed(unsigned seed, uint32_t n, int calls)
+{
+    std::mt19937 rng(seed);
+    h263mi_backend_cfg cfg{0, H263MI_CFG_PIPELINE_POST, nullptr};
+    h263mi_mixed *m = nullptr;
+    CHECK(h263mi_mixed_create(n, &cfg, &m) == H263MI_OK);
+    if (!m) return;
+    std::vector<void *> bufs(n, nullptr);
+    std::vector<size_t> caps(n, (size_t)g_w * g_h * 4);
+    for (uint32_t s = 0; s < n; s++) CHECK(h263mi_device_malloc(0, caps[s], &bufs[s]) == H263MI_OK);
+    std::vector<uint32_t> next(n, 0);
+    const uint32_t frames = (uint32_t)g_corpus[0].size();
+    for (int c = 0; c < calls; c++) {
+        std::vector<const uint8_t *> data(n, nullptr);
+        std::vector<size_t> len(n, 0), used(n, 0);
+        std::vector<int> rcs(n, 0);
+        for (uint32_t s = 0; s < n; s++) {
+            if (next[s] && rng() % 3 == 0) continue;
+            if (next[s] >= frames) next[s] = 0;
+            const std::vector<uint8_t> &p = g_corpus[(s + 3) % g_corpus.size()][next[s]];
+            data[s] = p.data();
+            len[s] = p.size();
+        }
+        const int rc = h263mi_mixed_decode_next_pictures(m, H263MI_SORENSON_SPARK_BITSTREAM, data.data(), len.data(), used.data(),
+                                                         1 + rng() % (g_max_threads < 12 ? g_max_threads : 12), rcs.data(), H263MI_STRENGTH_FROM_HEADER, (uint8_t *const *)bufs.data(),
+                                                         caps.data(), nullptr);
+        CHECK(rc == H263MI_OK);
+        for (uint32_t s = 0; s < n; s++)
+            if (data[s]) {
+                CHECK(rcs[s] == H263MI_OK);
+                if (rcs[s] == H263MI_OK) next[s]++;
+            }
+        if (c % 5 == 4) CHECK(h263mi_mixed_sync(m, nullptr) == H263MI_OK);
+    }
+    CHECK(h263mi_mixed_sync(m, nullptr) == H263MI_OK);
+    h263mi_mixed_destroy(m);
+    for (void *p : bufs) CHECK(h263mi_device_free(0, p) == H263MI_OK);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2 || !load_corpus(argv[1])) {
+        fprintf(stderr, "usage: tsan_driver <corpus.bin> [rounds]\n");
+        return 2;
+    }
+    const int rounds = argc > 2 ? atoi(argv[2]) : 2;
+    if (argc > 3) g_max_threads = (uint32_t)atoi(argv[3]);
+    const uint32_t n = (uint32_t)g_corpus.size();
+    for (int r = 0; r < rounds; r++) {
+        // one batch after the other: spinning and parking plans, teardown parked and mid-spin
+        drive_batch(100 + r, n, 40, /*pipeline=*/true, /*destroy_mid_spin=*/false);
+        drive_batch(200 + r, n, 25, /*pipeline=*/false, /*destroy_mid_spin=*/true);
+        drive_batch(300 + r, 3, 30, /*pipeline=*/true, /*destroy_mid_spin=*/true);        // fewer streams than threads
+        // distinct objects from distinct threads at the same time
+        std::thread t1(drive_batch, 400 + r, n, 30, true, true);
+        std::thread t2(drive_batch, 500 + r, n / 2 + 1, 30, false, false);
+        std::thread t3(drive_mixed, 600 + r, n, 20);
+        t1.join();
+        t2.join();
+        t3.join();
+    }
+    const int bad = g_failures.load();
+    fprintf(stderr, "tsan_driver: %d rounds, %d check failures\n", rounds, bad);
+    return bad ? 1 : 0;
+}

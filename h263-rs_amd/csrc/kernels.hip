@@ -299,7 +299,7 @@ __device__ __forceinline__ void recon_tail(const ReconArgs &a, ReconWave &s, int
 
 // One wave's share of the reconstruction: the 8 macroblocks at `p`.
 __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, int lane, WavePos p, const PrefetchPlan &plan,
-                                           const StreamWords &sw)
+                                           ScalarPtr32 kernarg_words)
 {
     if (p.mby >= (int)a0.L.mbh) return;
 #if H263MI_STOP_RECON == 9
@@ -309,7 +309,7 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     // it has one, and whether it takes part in this call at all (uniform: one scalar load per wave).
     ReconArgs a = a0;
     if (a0.stream_state || a0.words_inline) {
-        const uint32_t st = a0.words_inline ? sw.w[p.pic] : a0.stream_state[p.pic];      // (from the kernel arguments, or device memory)
+        const uint32_t st = a0.words_inline ? kernarg_words[p.pic] : a0.stream_state[p.pic];      // (kernel arguments, or device memory)
         if (st & STREAM_RECON_SKIP) return;
         const uint32_t set = st & STREAM_REF_SET1;
         a.ref = a0.frame_set[set];
@@ -368,7 +368,15 @@ __device__ __forceinline__ void recon_wave(const ReconArgs &a0, ReconWave &s, in
     PHASE_MARK(6);
 }
 
-__global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a, StreamWords sw)
+// The launch's StreamWords argument comes FIRST in every kernel below: it then sits at offset 0 of the kernarg segment, and a
+// wave reads its picture's word from there with ONE SCALAR load (indexing the by-value argument itself became a per-lane
+// flat load, and every pointer and strength selected from the word a vector value: +174 vector instructions in k_frame).
+__device__ __forceinline__ ScalarPtr32 kernarg_stream_words()
+{
+    return (ScalarPtr32)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+__global__ __launch_bounds__(RECON_THREADS) void k_recon(StreamWords, ReconArgs a)
 {
     __shared__ __attribute__((aligned(16))) ReconWave waves[RECON_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(RECON_THREADS) void k_recon(ReconArgs a, StreamWord
     p.cbase = 0;
     PrefetchPlan plan = {p, p};
     plan.far.pic = plan.near.pic = -1;              // (no prefetch in the stand-alone kernel)
-    recon_wave(a, waves[wave], lane, p, plan, sw);
+    recon_wave(a, waves[wave], lane, p, plan, kernarg_stream_words());
 }
 
 // Bands per picture: the XCDs that share one picture's work list (k_recon, k_frame).  Measured on the 64-stream bench
@@ -435,7 +443,7 @@ hipError_t launch_recon(const ReconArgs &args, hipStream_t stream, const uint32_
     a.bands = frame_bands(args.n_pictures);
     const uint32_t chunk = (upp + a.bands - 1) / a.bands, side_by_side = 8 / a.bands;
     hipLaunchKernelGGL(k_recon, dim3(chunk * 8, (args.n_pictures + side_by_side - 1) / side_by_side), dim3(RECON_THREADS), 0,
-                       stream, a, sw);
+                       stream, sw, a);
     return hipGetLastError();
 }
 
@@ -516,7 +524,7 @@ __device__ __forceinline__ void post_tile(const PostArgs &a, PostStrip &s, int l
 }
 
 template <bool STREAM_RGBA>
-__device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int lane, int sx, int ty, int pic, const StreamWords &sw)
+__device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int lane, int sx, int ty, int pic, ScalarPtr32 kernarg_words)
 {
     if (ty >= (int)a0.tiles_y) return;
 #if H263MI_STOP_POST == 9
@@ -524,7 +532,7 @@ __device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int 
 #endif
     PostArgs a = a0;
     if (a0.stream_state || a0.words_inline) {       // streams that differ (dev_common.h: STREAM_*): uniform
-        const uint32_t st = a0.words_inline ? sw.w[pic] : a0.stream_state[pic];
+        const uint32_t st = a0.words_inline ? kernarg_words[pic] : a0.stream_state[pic];
         if (st & STREAM_POST_SKIP) return;
         a.frames = a0.frame_set[(st & STREAM_POST_SET1) ? 1 : 0];
         a.strength = (st >> STREAM_STRENGTH_SHIFT) & STREAM_STRENGTH_MASK;      // this picture's own (deblock.rs:5-8)
@@ -536,7 +544,7 @@ __device__ __forceinline__ void post_wave(const PostArgs &a0, PostStrip &s, int 
     else post_tile<STREAM_RGBA, false>(a, s, lane, sx, ty, pic);
 }
 
-__global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a, StreamWords sw)
+__global__ __launch_bounds__(POST_THREADS) void k_post(StreamWords, PostArgs a)
 {
     __shared__ __attribute__((aligned(16))) PostStrip strips[POST_WAVES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave index: scalar
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a, StreamWords s
     const int pic = (int)blockIdx.y;
     const uint32_t gy = div_tiles_x(wg, a.tiles_x, a.inv_tiles_x);
     const int sx = (int)(wg - gy * a.tiles_x + a.wrap), ty = (int)gy * POST_GROUP + gw;      // (wrap: the first tile column is 1)
-    post_wave<false>(a, strips[wave], lane, sx, ty, pic, sw);
+    post_wave<false>(a, strips[wave], lane, sx, ty, pic, kernarg_stream_words());
 }
 
 // ---------------------------------------------------------------------------------------
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(PostArgs a, StreamWords s
 // at the same time on the same XCD: the planes are fetched from HBM once per frame instead of twice, and waves
 // bound by arithmetic and address work (reconstruction) share every CU with waves bound by stores (RGBA).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGeom fg, StreamWords sw)
+__global__ __launch_bounds__(64) void k_frame(StreamWords, ReconArgs ra, PostArgs pa, FrameGeom fg)
 {
 #if defined(H263MI_LDS_PAD)
     // experiment: what a larger LDS footprint per wave (fewer resident waves) costs
@@ -622,13 +630,13 @@ __global__ __launch_bounds__(64) void k_frame(ReconArgs ra, PostArgs pa, FrameGe
                 q.mby = (int)group3 * TILE_MBY + (int)(r3 & 1);
             }
         }
-        recon_wave(ra, lds.r, lane, p, plan, sw);
+        recon_wave(ra, lds.r, lane, p, plan, kernarg_stream_words());
     } else {
         if (H263MI_PRIO_POST) __builtin_amdgcn_s_setprio(H263MI_PRIO_POST);
 #if defined(H263MI_EXP_PLAIN_RGBA)
-        post_wave<false>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic, sw);
+        post_wave<false>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic, kernarg_stream_words());
 #else
-        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic, sw);
+        post_wave<true>(pa, lds.p, lane, (int)(r - fg.recon_per_group + pa.wrap), (int)group, pic, kernarg_stream_words());
 #endif
     }
 }
@@ -655,8 +663,8 @@ hipError_t launch_frame(const ReconArgs &rargs, const PostArgs &pargs, hipStream
     StreamWords sw{};
     ra.words_inline = pa.words_inline = inline_words(words, rargs.n_pictures, sw) ? 1u : 0u;
     const uint32_t chunk = (fg.groups * per_group + fg.bands - 1) / fg.bands, side_by_side = 8 / fg.bands;
-    hipLaunchKernelGGL(k_frame, dim3(chunk * 8, (rargs.n_pictures + side_by_side - 1) / side_by_side), dim3(64), 0, stream, ra,
-                       pa, fg, sw);
+    hipLaunchKernelGGL(k_frame, dim3(chunk * 8, (rargs.n_pictures + side_by_side - 1) / side_by_side), dim3(64), 0, stream, sw,
+                       ra, pa, fg);
     return hipGetLastError();
 }
 
@@ -671,7 +679,7 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, const uint32_t 
     a.inv_tiles_x = reciprocal_u32(args.tiles_x);
     const uint32_t groups_y = (args.tiles_y + POST_GROUP - 1) / POST_GROUP;
     const uint32_t upp = args.tiles_x * groups_y * (POST_GROUP / POST_WAVES), chunk = (upp + 7) / 8;
-    hipLaunchKernelGGL(k_post, dim3(chunk * 8, args.n_pictures), dim3(POST_THREADS), 0, stream, a, sw);
+    hipLaunchKernelGGL(k_post, dim3(chunk * 8, args.n_pictures), dim3(POST_THREADS), 0, stream, sw, a);
     return hipGetLastError();
 }
 

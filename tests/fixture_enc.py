@@ -7,7 +7,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from oracle.oracle import MB_RECORD_DTYPE
+# the record layout of include/h263mi.h (h263mi_mb_record, 32 bytes) -- kept here so that the workload generator imports
+# nothing of the oracle (bench.py may use the oracle as its checker only)
+MB_RECORD_DTYPE = np.dtype([
+    ("mb_type", "u1"), ("quant", "u1"), ("cbp", "u1"), ("kill", "u1"),
+    ("mv", "<i2", (4, 2)), ("intradc", "u1", (6,)), ("reserved", "u1", (2,)),
+    ("coeff_index", "<u4"),
+])
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None

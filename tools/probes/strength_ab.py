@@ -56,4 +56,6 @@ for rnd in range(rounds + 1):
             res[name].append(dt)
 base = float(np.mean(res["uniform 5"]))
 for name, v in res.items():
-    print("%-40s %.4f ms per frame index (%+.2f %%, spread %.4f)" % (name, np.mean(v), 100 * (np.mean(v) / base - 1), max(v) - min(v)), flush=True)
+    print("%-40s %.4f ms per frame index (%+.2f %%, median %.4f %+.2f %%, spread %.4f)  rounds: %s" % (
+        name, np.mean(v), 100 * (np.mean(v) / base - 1), np.median(v), 100 * (np.median(v) / float(np.median(res["uniform 5"])) - 1),
+        max(v) - min(v), " ".join("%.4f" % x for x in v)), flush=True)

@@ -741,12 +741,25 @@ def stub_main(args, rank, world):
         dist.all_gather_object(all_streams, mine)
     else:
         all_streams = [mine]
+    # where the library would place this rank's host side (NUMA node of its GPU, its slice of that node's cores): the real
+    # code path of a batch (worker_pool.cpp: host_placement) on the topology H263MI_SYSFS_ROOT / H263MI_STUB_PCI_IDS describe
+    placement = None
+    if os.environ.get("H263MI_STUB_PCI_IDS"):
+        import h263mi
+        node, cpus = h263mi.debug_host_placement(os.environ["H263MI_STUB_PCI_IDS"].split(","), rank, shard.local_world_size(world))
+        placement = [None] * world
+        mine_pl = {"rank": rank, "node": node, "cpus": cpus}
+        if dist is not None:
+            dist.all_gather_object(placement, mine_pl)
+        else:
+            placement = [mine_pl]
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": pictures * MP_PER_PICTURE / elapsed, "unit": "MP/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "data": "stub (no GPU work)",
                           "pictures": pictures, "scaling": "strong" if strong else "weak",
                           "streams_of_rank": all_streams, "parser_threads_per_rank": threads,
                           "cpu_budget": physical_cores()[0], "local_world_size": shard.local_world_size(world),
+                          "placement_per_rank": placement,
                           "e2e": {"pictures_per_s": e2e_rate, "pictures": e2e_units, "seconds": e2e_seconds}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <string>
 #include <thread>
 
 using namespace h263mi;
@@ -550,6 +551,28 @@ int h263mi_batch_host_placement(const h263mi_batch *b, int *device_numa_node, in
         }
     }
     if (n_pool_cpus) *n_pool_cpus = k;
+    return H263MI_OK;
+}
+
+// TEST HOOK (no HIP call, usable without a device): what a batch on device `device` of a host with the PCI functions pci_ids[0 ..
+// n_devices) would get as its host placement when `ranks` processes share the node, on the sysfs tree under `sysfs_root`
+// (NULL = H263MI_SYSFS_ROOT or /sys).  *node = the NUMA node (-1: none), cpus / *n_cpus as in h263mi_batch_host_placement.
+// tests/test_numa_placement.py and the 8-rank stand-in of bench.py use it on a made-up two-socket topology.
+int h263mi_debug_host_placement(const char *const *pci_ids, uint32_t n_devices, int device, uint32_t ranks, const char *sysfs_root,
+                                int *node, uint16_t *cpus, uint32_t cpus_cap, uint32_t *n_cpus)
+{
+    if (!pci_ids || !node || !n_cpus) return H263MI_ERR_INVALID_ARGUMENT;
+    std::vector<std::string> ids;
+    for (uint32_t d = 0; d < n_devices; d++) ids.push_back(pci_ids[d] ? pci_ids[d] : "");
+    const HostPlacement p = host_placement(ids, device, ranks ? ranks : 1, sysfs_root);
+    *node = p.node;
+    uint32_t k = 0;
+    for (int c = 0; c < CPU_SETSIZE && p.have_cpus; c++) {
+        if (!CPU_ISSET(c, &p.cpus)) continue;
+        if (cpus && k < cpus_cap) cpus[k] = (uint16_t)c;
+        k++;
+    }
+    *n_cpus = k;
     return H263MI_OK;
 }
 

@@ -84,7 +84,7 @@ EXPORTS = [
     # ABI 7: one post-filter strength per stream, explicit host share, NUMA placement report
     "h263mi_batch_decode_ps", "h263mi_batch_decode_events_ps", "h263mi_batch_render_rgba_ps",
     "h263mi_batch_decode_next_pictures_ps", "h263mi_mixed_decode_next_pictures_ps",
-    "h263mi_set_ranks_per_node", "h263mi_batch_host_placement",
+    "h263mi_set_ranks_per_node", "h263mi_batch_host_placement", "h263mi_debug_host_placement",
 ]
 STRENGTH_FROM_HEADER = 0xFF
 CFG_OVERLAP_POST, CFG_PIPELINE_POST, CFG_TRUSTED_ARRAYS = 1, 2, 4
@@ -243,6 +243,7 @@ def lib():
         L.h263mi_set_ranks_per_node.argtypes = [u32]
         L.h263mi_set_ranks_per_node.restype = None
         L.h263mi_batch_host_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), vp, u32]
+        L.h263mi_debug_host_placement.argtypes = [vp, u32, i32, u32, C.c_char_p, C.POINTER(i32), vp, u32, C.POINTER(u32)]
         L.h263mi_default_parser_threads.restype = u32
         L.h263mi_default_parser_threads.argtypes = [u32, C.POINTER(u32)]
         _lib = L
@@ -784,6 +785,16 @@ def synth_picture_host(kind, width, height, stream_id, frame_idx):
     _check(lib().h263mi_synth_picture_host(kind, width, height, stream_id, frame_idx, _p(mbs), _p(coeffs), total * 6,
                                            C.byref(n)), "synth_picture_host")
     return mbs, coeffs[:n.value].copy()
+
+
+def debug_host_placement(pci_ids, device, ranks, sysfs_root=None):
+    """h263mi_debug_host_placement (no GPU needed): (NUMA node, CPUs) a batch on `device` would be placed on"""
+    arr = (C.c_char_p * len(pci_ids))(*[p.encode() for p in pci_ids])
+    node, k = C.c_int(-1), C.c_uint32(0)
+    cpus = (C.c_uint16 * 1024)()
+    _check(lib().h263mi_debug_host_placement(arr, len(pci_ids), device, ranks, sysfs_root.encode() if sysfs_root else None,
+                                             C.byref(node), cpus, 1024, C.byref(k)), "debug_host_placement")
+    return node.value, [int(cpus[i]) for i in range(min(k.value, 1024))]
 
 
 def set_ranks_per_node(ranks):

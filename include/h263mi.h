@@ -436,6 +436,11 @@ void h263mi_set_ranks_per_node(uint32_t ranks);
  * (*n_pool_cpus = how many, 0 = not confined / no threads yet; cpus, may be NULL, receives up to cpus_cap of their numbers). */
 int h263mi_batch_host_placement(const h263mi_batch *b, int *device_numa_node, int *staging_numa_node, uint32_t *n_pool_cpus,
                                 uint16_t *cpus, uint32_t cpus_cap);
+/* TEST HOOK (makes no HIP call): the placement a batch on device `device` would get on a host whose devices have the PCI
+ * addresses pci_ids[0 .. n_devices) when `ranks` processes share the node, read from the sysfs tree under sysfs_root (NULL =
+ * H263MI_SYSFS_ROOT, else /sys).  *node: the NUMA node, -1 = none. */
+int h263mi_debug_host_placement(const char *const *pci_ids, uint32_t n_devices, int device, uint32_t ranks, const char *sysfs_root,
+                                int *node, uint16_t *cpus, uint32_t cpus_cap, uint32_t *n_cpus);
 int h263mi_batch_decode_next_pictures(h263mi_batch *b, uint32_t decoder_options, const uint8_t *const *data,
                                       const size_t *len, size_t *consumed, uint32_t n_threads);
 /*

@@ -55,8 +55,9 @@ struct h263mi_state {
 };
 
 // n_event_words > 0: sparse transport -- no dense blocks anywhere, the reconstruction waves read the events
-static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n_blocks, size_t n_event_words)
+static int state_ensure_staging(h263mi_state::Staging &g, size_t n_mbs, size_t n_blocks, size_t n_event_words, const HostPlacement &where)
 {
+    PlacementScope near_device(where);           // pinned memory on the NUMA node of the state's GPU (worker_pool.h)
     if (n_mbs > g.cap_mbs) {
         if (g.h_mbs) (void)hipHostFree(g.h_mbs);
         if (g.d_mbs) (void)hipFree(g.d_mbs);
@@ -201,7 +202,7 @@ static int submit_records(h263mi_state *s, const h263mi_picture_desc *desc, cons
     h263mi_batch *b = same_size ? s->b : fresh.get();
     h263mi_state::Staging &g2 = s->stg[s->next_slot & 1];
     const size_t event_words = sparse ? n_coeff_blocks + 1 + n_events : 0;
-    RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1, event_words));
+    RC_TRY(state_ensure_staging(g2, total, n_coeff_blocks ? n_coeff_blocks : 1, event_words, b->placement));
     HIP_TRY(hipEventSynchronize(g2.done));       // the kernel that read this slot two pictures ago is done
 
     // (h263mi_decode_next_picture has its parser write the records straight into this slot)
@@ -277,7 +278,7 @@ int h263mi_decode_next_picture(h263mi_state *s, const uint8_t *data, size_t len,
         DeviceGuard g(s->cfg.device_id);
         h263mi_state::Staging &g2 = s->stg[s->next_slot & 1];
         const size_t total = (size_t)s->b->L.mbw * s->b->L.mbh;
-        if (g.ok && state_ensure_staging(g2, total, 1, 1) == H263MI_OK && hipEventSynchronize(g2.done) == hipSuccess) {
+        if (g.ok && state_ensure_staging(g2, total, 1, 1, s->b->placement) == H263MI_OK && hipEventSynchronize(g2.done) == hipSuccess) {
             pic.mbs_ext = g2.h_mbs;
             pic.mbs_ext_cap = total;
         }

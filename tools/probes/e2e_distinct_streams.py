@@ -11,6 +11,6 @@ stream = torch.cuda.current_stream().cuda_stream
 d_rgba = h263mi.DeviceBuffer(64 * bench.RGBA_BYTES, 0)
 threads, quota = h263mi.default_parser_threads(64)
 for k in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16]:
-    e = bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, n_distinct=k, parser_threads=threads, realistic=True)
+    e = bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, n_distinct=k, parser_threads=threads, corpus="kinds")
     print("n_distinct %2d: %8.0f pictures/s on %d threads, one parser thread %6.0f, parity %s" % (
         k, e["pictures_per_s"], threads, e["one_parser_thread_pictures_per_s"], e["parity_vs_oracle"]), flush=True)

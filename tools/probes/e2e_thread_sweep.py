@@ -13,7 +13,7 @@ def stat():
         return {}
 for thr in (8, 12, 14, 15, 16, 20):
     s0 = stat()
-    d = bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, parser_threads=thr, realistic=True)
+    d = bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, parser_threads=thr, corpus="kinds")
     s1 = stat()
     print(thr, "threads:", d["pictures_per_s"], "pictures/s; one thread", d["one_parser_thread_pictures_per_s"],
           "throttled periods +%d, +%.1f ms" % (int(s1.get("nr_throttled", 0)) - int(s0.get("nr_throttled", 0)),

@@ -19,5 +19,5 @@ torch.cuda.set_device(0)
 stream = torch.cuda.current_stream().cuda_stream
 d_rgba = h263mi.DeviceBuffer(64 * bench.RGBA_BYTES, 0)
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else None           # parser threads (default: the container's CPU quota)
-print(json.dumps(bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, parser_threads=threads)), flush=True)
-print(json.dumps(bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, parser_threads=threads, realistic=True)), flush=True)
+print(json.dumps(bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, parser_threads=threads, corpus="dense", n_distinct=4)), flush=True)
+print(json.dumps(bench.e2e_bitstream(h263mi, 64, 0, stream, d_rgba, parser_threads=threads, corpus="kinds")), flush=True)

@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -476,6 +478,21 @@ int make_strengths(uint8_t strength, const uint8_t *strengths, uint32_t n, bool 
 // Where the host side of device `dev` belongs: the PCI addresses of the visible devices -> worker_pool.cpp (sysfs)
 HostPlacement placement_of_device(int dev)
 {
+    // looked up once per (device, ranks per node, switches): a mixed-size set makes a batch whenever a class is made or
+    // rebuilt -- out of untrusted bitstreams -- and the look-up reads a few hundred sysfs files
+    static std::mutex cache_mutex;
+    static std::map<std::string, HostPlacement> cache;
+    const uint32_t ranks = host_thread_plan(1, 0).ranks;
+    std::string key = std::to_string(dev) + "|" + std::to_string(ranks);
+    for (const char *name : {"H263MI_NUMA", "H263MI_NUMA_NODE", "H263MI_SYSFS_ROOT"}) {
+        const char *v = getenv(name);
+        key += std::string("|") + (v ? v : "");
+    }
+    {
+        std::lock_guard<std::mutex> l(cache_mutex);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HostPlacement();
     std::vector<std::string> ids((size_t)count);
@@ -484,7 +501,10 @@ HostPlacement placement_of_device(int dev)
         if (hipDeviceGetPCIBusId(id, (int)sizeof id, d) == hipSuccess) ids[(size_t)d] = id;
         else (void)hipGetLastError();
     }
-    return host_placement(ids, dev, host_thread_plan(1, 0).ranks);
+    const HostPlacement p = host_placement(ids, dev, ranks);
+    std::lock_guard<std::mutex> l(cache_mutex);
+    cache[key] = p;
+    return p;
 }
 
 int batch_create(uint32_t n_streams, uint32_t w, uint32_t h, const h263mi_backend_cfg *cfg, h263mi_batch **out)

@@ -1,6 +1,9 @@
 #!/bin/bash
 # A/B builds of libh263mi.so on the same GPU box: interleaved bench runs, per-kernel averages.
 # usage: ROUNDS=3 bash tools/ab.sh <libA.so> <libB.so> [<libC.so> ...]
+# (ab_libs/ is in .gpurunignore: stale variants do not travel with every call.  Build the variants ON the box -- tools/build_variant.sh,
+#  hipcc is there -- or take the line out of .gpurunignore for the one call that needs libraries built here, e.g. those of earlier rounds:
+#  `git archive <round commit> h263-rs_amd include | tar -x -C /tmp/src_rN`, build, copy to ab_libs/; tools/ab_inproc.py runs them beside HEAD.)
 N=${ROUNDS:-3}
 for i in $(seq 1 $N); do
   for L in "$@"; do

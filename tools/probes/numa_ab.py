@@ -43,7 +43,7 @@ for rnd in range(rounds):
             os.environ.pop(k, None)
         os.environ.update(env)
         for corpus in ("kinds", "distinct"):
-            e = bench.e2e_bitstream(h263mi, N, 0, stream, d_rgba, corpus=corpus, n_distinct=8, parser_threads=threads, min_seconds=0.5)
+            e = bench.e2e_bitstream(h263mi, N, 0, stream, d_rgba, corpus=corpus, n_distinct=8, parser_threads=threads, min_seconds=1.0)
             assert e["parity_vs_oracle"] == "ok"
             res[m][corpus].append(e["pictures_per_s"])
             res[m]["placement"] = e["host_placement"]

@@ -504,3 +504,49 @@ def test_hand_derived_pictures_with_content_decode_to_what_the_reference_text_gi
         assert_planes_equal(bt.copy_yuv(s), ref, "batch stream %d" % s)
     bt.close()
     st.close()
+
+
+def test_more_streams_than_fit_the_kernel_arguments_take_their_words_from_device_memory():
+    """a launch of up to 64 pictures carries the streams' words in its kernel arguments; a batch of 80 streams puts them into
+    device memory (a small copy in front of the launch): same results"""
+    n, w, h = 80, 48, 32
+    st = _Streams(n, w, h, seed=611)
+    b = h263mi.Batch(n, w, h, pipeline_post=True)
+    bufs = [h263mi.DeviceBuffer(n * w * h * 4) for _ in range(2)]
+    wants = []
+    for f in range(2):
+        used, rcs = b.decode_next_pictures_ex(st.pictures(f == 0), n_threads=4, strength=h263mi.STRENGTH_FROM_HEADER, d_rgba=bufs[f].ptr)
+        assert not any(rcs)
+        wants.append([want_rgba(st.refs[s], w, header_strength(st.q[s], st.flag[s])) for s in range(n)])
+    b.sync()
+    for f in range(2):
+        for s in range(n):
+            assert np.array_equal(bufs[f].download(w * h * 4, s * w * h * 4), wants[f][s]), (f, s)
+    b.close()
+
+
+def test_the_bench_path_with_64_strengths_at_1080p_matches_the_oracle_on_sampled_streams():
+    """the headline launch (64 x 1080p, events, k_frame) with 64 DIFFERENT strengths through h263mi_batch_decode_events_ps
+    and _decode_ps: planes and RGBA of sampled streams after a chain of P pictures against the oracle"""
+    import bench
+    n, frames = 64, 4
+    strengths = [int(h263mi.quant_to_strength()[1 + (5 * s) % 31]) if s % 7 else 0 for s in range(n)]
+    wl = bench.Workload(h263mi, n, frames, 0, 0, None, events=True)
+    b = h263mi.Batch(n, bench.W, bench.H, pipeline_post=True)
+    d_rgba = h263mi.DeviceBuffer(n * bench.RGBA_BYTES)
+    for fr in wl.frames:
+        if fr.get("first") is not None:
+            b.decode_events(fr["ptype"], fr["mbs"].ptr, fr["first"].ptr, fr["ev"].ptr, fr["base"].ptr, fr["blocks"], 0, d_rgba.ptr, None,
+                            n_events=fr["n_events"], strengths=strengths)
+        else:
+            b.decode(fr["ptype"], fr["mbs"].ptr, fr["co"].ptr, fr["base"].ptr, fr["blocks"], 0, d_rgba.ptr, None, strengths=strengths)
+    b.sync()
+    for s in (0, 7, 33, 63):
+        ref = None
+        for f in range(frames):
+            mbs, co = h263mi.synth_picture_host(h263mi.SYNTH_I_MIXED if f == 0 else h263mi.SYNTH_P, bench.W, bench.H, s, f)
+            rc, ref = orc.decode_picture(bench.W, bench.H, mbs, co, ref)
+            assert rc == 0
+        assert_planes_equal(b.copy_yuv(s), ref, "stream %d" % s)
+        assert np.array_equal(d_rgba.download(bench.RGBA_BYTES, s * bench.RGBA_BYTES), want_rgba(ref, bench.W, strengths[s])), s
+    b.close()

@@ -21,6 +21,9 @@ class FuzzMismatch(AssertionError):
     pass
 
 
+Q2S = [int(v) for v in orc.quant_to_strength()]
+
+
 def _dev(arr):
     arr = np.ascontiguousarray(arr)
     d = h263mi.DeviceBuffer(max(arr.nbytes, 16))
@@ -66,24 +69,29 @@ def fuzz_batch(rng, w, h, seed, n_pic, n_px):
             at += len(c)
         co = np.concatenate(co_all) if at else np.zeros((0, 64), np.int16)
         strength = int(rng.integers(0, 13))
+        # (ABI 7) one strength per stream in half of the frames; the sizes of the arrays given, or left to the allocations
+        strengths = [int(v) for v in rng.integers(0, 13, n)] if rng.random() < 0.5 else None
+        told = rng.random() < 0.5
         pt = h263mi.PICTURE_I if intra else h263mi.PICTURE_P
         d_m, d_b = _dev(np.concatenate(mbs_all)), _dev(np.array(base, np.uint64))
         if events:
             first, ev = h263mi.events_from_dense(co, np.concatenate(blk_intra_all) if at else None)
             d_f, d_e = _dev(first), _dev(np.concatenate([ev, np.zeros(8, np.uint32)]))
             keep.append((d_m, d_b, d_f, d_e))
-            b.decode_events(pt, d_m.ptr, d_f.ptr, d_e.ptr, d_b.ptr, max(at, 1), strength, d_rgba[f].ptr)
+            b.decode_events(pt, d_m.ptr, d_f.ptr, d_e.ptr, d_b.ptr, max(at, 1) if told else 0, strength, d_rgba[f].ptr,
+                            n_events=len(ev) if told else 0, strengths=strengths)
         else:
             d_c = _dev(co if at else np.zeros((1, 64), np.int16))
             keep.append((d_m, d_b, d_c))
-            b.decode(pt, d_m.ptr, d_c.ptr, d_b.ptr, max(at, 1), strength, d_rgba[f].ptr)
+            b.decode(pt, d_m.ptr, d_c.ptr, d_b.ptr, max(at, 1) if told else 0, strength, d_rgba[f].ptr, strengths=strengths)
         # a pipelined batch renders picture f inside the launch that reconstructs picture f + 1 -- unless a sync comes
         # first, which renders it with a launch of its own: both orders occur
         if rng.random() < 0.3:
             b.sync()
         want.append([])
         for s_ in range(n):
-            planes = refs[s_] if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(refs[s_], (w, cw, cw)))
+            st_ = strengths[s_] if strengths else strength
+            planes = refs[s_] if st_ == 0 else tuple(orc.deblock(p, pw, st_) for p, pw in zip(refs[s_], (w, cw, cw)))
             want[f].append(orc.yuv420_to_rgba(*planes, w))
         n_pic += n
         n_px += n * w * h
@@ -105,6 +113,90 @@ def fuzz_batch(rng, w, h, seed, n_pic, n_px):
     return n_pic, n_px
 
 
+def fuzz_hostile(rng, w, h, seed, n_pic, n_px):
+    """HOSTILE device arrays with no sizes given (ABI 7: checked by default, the allocations bound what is read): the block
+    offsets, the events' positions in the pool, coded-block indices and per-stream bases of SOME streams of a batch are
+    overwritten with garbage (huge values, descending offsets, values just past the end).  Nothing may fault; a stream whose
+    arrays were left alone decodes to the oracle's planes; a stream that was hit is either rejected (its previous picture is
+    its last picture again) or -- garbage that happens to stay inside the arrays -- decodes SOMETHING; and the batch decodes
+    a clean picture afterwards."""
+    import simlib
+    n = int(rng.choice([1, 2, 5, 8]))
+    b = h263mi.Batch(n, w, h, pipeline_post=bool(rng.integers(0, 2)))
+    what = ("hostile", w, h, n, seed)
+    recs, refs, at, base = [], [], 0, []
+    for s_ in range(n):
+        m, c = recgen.intra_picture(w, h, seed=int(rng.integers(0, 1 << 30)), max_level=int(rng.choice([40, 1023])))
+        rc, ref = orc.decode_picture(w, h, m, c, None)
+        assert rc == 0
+        recs.append((simlib.pad_records(m, w, h), c))
+        refs.append(ref)
+        base.append(at)
+        at += len(c)
+    mbs = np.concatenate([r[0] for r in recs])
+    co = np.concatenate([r[1] for r in recs])
+    first, ev = h263mi.events_from_dense(co, np.ones(len(co), bool))
+    good = (_dev(mbs), _dev(first), _dev(ev if len(ev) else np.zeros(4, np.uint32)), _dev(np.array(base, np.uint64)))
+
+    def clean():
+        b.decode_events(h263mi.PICTURE_I, good[0].ptr, good[1].ptr, good[2].ptr, good[3].ptr)
+        if any(b.sync_streams()):
+            raise FuzzMismatch("clean picture rejected: %r" % (what,))
+        for s_ in range(n):
+            for g, e, name in zip(b.copy_yuv(s_), refs[s_], "Y Cb Cr".split()):
+                if not (np.asarray(g) == e).all():
+                    raise FuzzMismatch("clean picture differs: %r stream %d %s" % (what, s_, name))
+
+    clean()
+    per = len(mbs) // n
+    for attempt in range(int(rng.integers(2, 6))):
+        hit = set(int(v) for v in rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False))
+        m2, f2, b2 = mbs.copy(), first.copy(), np.array(base, np.uint64)
+        for s_ in hit:
+            lo, hi = base[s_], (base[s_ + 1] if s_ + 1 < n else at)
+            kind = int(rng.integers(0, 5))
+            junk = [0xffffffff, 0xfffffff0, len(ev), len(ev) + 1, len(ev) + 64, 1 << 28, 0x7fffffff]
+            # (entries lo and hi of the offsets are shared with the neighbouring streams' blocks: only lo + 1 .. hi - 1 are this
+            # stream's own)
+            if kind in (0, 1, 4) and hi - lo < 4:
+                kind = 2
+            if kind == 0:                        # garbage offsets inside this stream's blocks
+                k = rng.integers(lo + 1, hi, size=min(4, hi - lo - 1))
+                f2[k] = rng.choice(junk, size=len(k))
+            elif kind == 1:                      # a descending pair
+                k = int(rng.integers(lo + 1, hi - 1))
+                f2[k], f2[k + 1] = f2[k + 1] + 7, f2[k]
+            elif kind == 2:                      # coded-block indices far outside / just outside the pool
+                k = s_ * per + rng.integers(0, per, size=3)
+                m2["coeff_index"][k] = rng.choice([at, at + 1, 1 << 24, 0xffffffff], size=3)
+                m2["cbp"][k] |= 1
+            elif kind == 3:                      # the stream's base beyond the pool
+                b2[s_] = int(rng.choice([at, at + 5, 1 << 40, (1 << 64) - 1]))
+            else:                                # every offset of the stream shifted far out
+                f2[lo + 1:hi] = (f2[lo + 1:hi].astype(np.uint64) + int(rng.choice([len(ev), 1 << 27]))).astype(np.uint32)
+        d = (_dev(m2), _dev(f2), _dev(b2))
+        b.decode_events(h263mi.PICTURE_I, d[0].ptr, d[1].ptr, good[2].ptr, d[2].ptr)
+        rcs = b.sync_streams()
+        for s_ in range(n):
+            if s_ not in hit:
+                if rcs[s_] != 0:
+                    raise FuzzMismatch("untouched stream %d rejected (%d): %r attempt %d" % (s_, rcs[s_], what, attempt))
+                for g, e, name in zip(b.copy_yuv(s_), refs[s_], "Y Cb Cr".split()):
+                    if not (np.asarray(g) == e).all():
+                        raise FuzzMismatch("untouched stream %d differs: %r attempt %d %s" % (s_, what, attempt, name))
+            elif rcs[s_] not in (0, h263mi.ERR_INVALID_ARGUMENT):
+                raise FuzzMismatch("hit stream %d: verdict %d: %r" % (s_, rcs[s_], what))
+        for x in d:
+            x.free()
+        clean()
+        n_pic += 2 * n
+        n_px += 2 * n * w * h
+    b.close()
+    for x in good:
+        x.free()
+    return n_pic, n_px
+
+
 def fuzz_mixed(rng, seed, n_pic, n_px):
     """A set of streams of different (and changing) picture sizes behind one call (h263mi_mixed): per call every stream
     does one of -- nothing, a P picture, a key frame of its size, a key frame of ANOTHER size (the stream moves), a P picture
@@ -113,6 +205,7 @@ def fuzz_mixed(rng, seed, n_pic, n_px):
     n = int(rng.integers(2, 8))
     pipeline = bool(rng.integers(0, 2))
     strength = int(rng.integers(0, 13))
+    from_header = bool(rng.integers(0, 2))       # (ABI 7) every picture rendered with what its own header asks for
     palette = [(176, 144), (352, 288), (96, 80), (128, 96), (int(rng.integers(17, 200)), int(rng.integers(17, 150))),
                (4 * int(rng.integers(5, 60)), 4 * int(rng.integers(5, 40)))]
     m = h263mi.MixedBatch(n, pipeline_post=pipeline)
@@ -146,7 +239,8 @@ def fuzz_mixed(rng, seed, n_pic, n_px):
                 mbs, co = recgen.inter_picture(wh[0], wh[1], seed=sd, mv_range=32, p_4v=float(rng.choice([0.0, 0.3])), p_intra=0.05,
                                                p_coded=float(rng.choice([0.1, 0.5])), quant=q, max_level=int(rng.choice([60, 1023])))
             mbs = make_codable(mbs, q, sd, 0 if intra else 1)
-            datas.append(enc.encode_picture(wh[0], wh[1], 0 if intra else 1, q, mbs, co, temporal_reference=c))
+            flag = int(rng.integers(0, 2))
+            datas.append(enc.encode_picture(wh[0], wh[1], 0 if intra else 1, q, mbs, co, temporal_reference=c, deblock_flag=flag))
             if not intra and refs[s_] is None:
                 expect.append(h263mi.ERR_UNCODED_IFRAME_BLOCKS)
             elif not intra and wh != size[s_]:
@@ -157,11 +251,13 @@ def fuzz_mixed(rng, seed, n_pic, n_px):
                 size[s_] = wh
                 expect.append(0)
                 cw = (wh[0] + 1) // 2
-                planes = refs[s_] if strength == 0 else tuple(orc.deblock(p, pw, strength) for p, pw in zip(refs[s_], (wh[0], cw, cw)))
+                st_ = (Q2S[q] if flag else 0) if from_header else strength
+                planes = refs[s_] if st_ == 0 else tuple(orc.deblock(p, pw, st_) for p, pw in zip(refs[s_], (wh[0], cw, cw)))
                 want.append((c, s_, wh, orc.yuv420_to_rgba(*planes, wh[0])))
                 n_pic += 1
                 n_px += wh[0] * wh[1]
-        used, rcs, descs = m.decode_next_pictures(datas, n_threads=int(rng.integers(1, 4)), strength=strength, rgba=rgba[c])
+        used, rcs, descs = m.decode_next_pictures(datas, n_threads=int(rng.integers(1, 4)),
+                                                  strength=h263mi.STRENGTH_FROM_HEADER if from_header else strength, rgba=rgba[c])
         if list(rcs) != expect:
             raise FuzzMismatch("mixed set: call %d return codes %s, expected %s: %r" % (c, list(rcs), expect, what))
         if m.size_classes() > 2 * n:
@@ -209,6 +305,9 @@ def run(budget=60.0, seed=1, verbose=True):
                             rng.integers(64, 420), 4 * rng.integers(16, 100)]))
         if rng.random() < (1.0 if os.environ.get("H263MI_FUZZ_MIXED_ONLY") else 0.08):      # (the switch: a run of mixed sets only)
             n_pic, n_px = fuzz_mixed(rng, seed, n_pic, n_px)
+            continue
+        if rng.random() < 0.07:
+            n_pic, n_px = fuzz_hostile(rng, min(max(w, 17), 300), min(max(h, 17), 200), seed, n_pic, n_px)
             continue
         if rng.random() < 0.2:
             # a BATCH of streams in lock step (h263mi_batch_decode / _decode_events), plain or frame-pipelined: the launch

@@ -141,6 +141,13 @@ static void test_state_api()                       // state.rs:42-78, gather.rs:
     h263::PinnedBuffer pinned((size_t)176 * 144 * 4);
     st.render_rgba_into_pinned(5, pinned.data());
     ASSERT_EQ(std::vector<uint8_t>(pinned.data(), pinned.data() + pinned.size()), st.render_rgba(5), "pinned render == render");
+    // (ABI 7) the strength the picture's own header asks for: QUANT_TO_STRENGTH[as_header().quantizer] when USE_DEBLOCKER is
+    // set, none otherwise (deblock.rs:5-8, picture.rs:61-64) -- what a consumer of the reference computes per picture
+    ASSERT_EQ(st.render_rgba(h263::H263State::kStrengthFromHeader), st.render_rgba(0), "header without USE_DEBLOCKER: no deblocking");
+    st.submit_picture(h263mi_picture_desc{176, 144, H263MI_PICTURE_I, 8, 1, 0, 9, 0}, mbs, {});
+    ASSERT_EQ((int)deblock::QUANT_TO_STRENGTH[8], 4, "Table J.2: quantiser 8 -> strength 4");
+    ASSERT_EQ(st.render_rgba(h263::H263State::kStrengthFromHeader), st.render_rgba(deblock::QUANT_TO_STRENGTH[8]),
+              "header with USE_DEBLOCKER, quantiser 8: strength 4");
 }
 
 static uint64_t fnv1a64(const std::vector<uint8_t> &b)
@@ -203,6 +210,22 @@ static void test_state_set()
     o = set.decode_next_pictures({pic[0][1]->data.data(), nullptr, nullptr}, {pic[0][1]->data.size(), 0, 0});
     ASSERT_EQ(o.result[0], H263MI_ERR_UNCODED_IFRAME_BLOCKS, "reset stream needs an I picture");
     ASSERT_EQ(fnv1a64(set.get_last_picture(1)->as_luma()), pic[1][1]->sums[0], "stream 1 keeps its picture");
+    // (ABI 7) one strength per stream: what each consumer composes for ITS stream -- deblock(plane, strength[s]) x 3 +
+    // yuv420_to_rgba (the plain functions above, held to the reference's own vectors) -- is what the set renders for it
+    const std::vector<uint8_t> strengths = {3, 9, 0};
+    o = set.decode_next_pictures({pic[0][0]->data.data(), pic[1][0]->data.data(), nullptr},
+                                 {pic[0][0]->data.size(), pic[1][0]->data.size(), 0}, 0, &d_rgba, &cap, 0, &strengths);
+    ASSERT_EQ(o.all_ok(), true, "key frames again, each stream with its own strength");
+    for (int rc : set.sync()) ASSERT_EQ(rc, H263MI_OK, "device verdicts");
+    for (int s2 = 0; s2 < 2; s2++) {
+        auto p = set.get_last_picture((uint32_t)s2);
+        const size_t w = p->luma_samples_per_row(), cw = p->chroma_samples_per_row();
+        const auto y = deblock::deblock(p->as_luma(), w, strengths[(size_t)s2]);
+        const auto cb = deblock::deblock(p->as_chroma_b(), cw, strengths[(size_t)s2]);
+        const auto cr = deblock::deblock(p->as_chroma_r(), cw, strengths[(size_t)s2]);
+        const auto want = yuv::bt601::yuv420_to_rgba(y, cb, cr, w);
+        ASSERT_EQ((s2 ? rgba1 : rgba0).download(want.size()), want, "per-stream strength == the consumer's own composition");
+    }
 }
 
 int main()

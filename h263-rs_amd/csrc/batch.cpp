@@ -602,6 +602,26 @@ static int bound_device_arrays(const h263mi_batch *b, const h263mi_mb_record *d_
     return H263MI_OK;
 }
 
+// The caller's OUTPUT buffers of the same entry points: where the runtime knows the allocation a pointer lies in, it must hold
+// what the launch will write (n pictures of RGBA / of filtered planes); a pointer it does not know (the device view of
+// registered host memory, another runtime's memory) is taken as it is.  Checked batches only.
+static int bound_output_buffers(const h263mi_batch *b, const uint8_t *d_rgba, const uint8_t *d_deblocked)
+{
+    if (b->trusted_arrays) return H263MI_OK;
+    const size_t rgba_bytes = (size_t)b->n * b->L.width * b->L.height * 4;
+    const size_t plane_bytes = (size_t)b->n * ((size_t)b->L.width * b->L.height + 2 * (size_t)b->L.cwidth * b->L.cheight);
+    size_t left = 0;
+    if (d_rgba) {
+        const int rc = bytes_behind(d_rgba, &left);
+        if (rc == H263MI_ERR_OUT_OF_MEMORY || (rc == H263MI_OK && left < rgba_bytes)) return rc == H263MI_OK ? H263MI_ERR_INVALID_ARGUMENT : rc;
+    }
+    if (d_deblocked) {
+        const int rc = bytes_behind(d_deblocked, &left);
+        if (rc == H263MI_ERR_OUT_OF_MEMORY || (rc == H263MI_OK && left < plane_bytes)) return rc == H263MI_OK ? H263MI_ERR_INVALID_ARGUMENT : rc;
+    }
+    return H263MI_OK;
+}
+
 }  // namespace h263mi
 
 // =========================================================================================
@@ -658,6 +678,7 @@ int h263mi_batch_decode_ps(h263mi_batch *b, uint8_t picture_type, const h263mi_m
     src.coeffs = d_coeffs;
     src.coeff_base = d_coeff_base;
     RC_TRY(bound_device_arrays(b, d_mbs, coeff_pool_blocks, 0, src));
+    RC_TRY(bound_output_buffers(b, d_rgba, d_deblocked));
     return batch_decode_device(b, picture_type, d_mbs, src, st, d_rgba, d_deblocked);
 }
 
@@ -684,6 +705,7 @@ int h263mi_batch_decode_events_ps(h263mi_batch *b, uint8_t picture_type, const h
     src.events = d_events;
     src.coeff_base = d_coeff_base;
     RC_TRY(bound_device_arrays(b, d_mbs, coeff_pool_blocks, n_events, src));
+    RC_TRY(bound_output_buffers(b, d_rgba, d_deblocked));
     return batch_decode_device(b, picture_type, d_mbs, src, st, d_rgba, d_deblocked);
 }
 
@@ -702,6 +724,7 @@ int h263mi_batch_render_rgba_ps(h263mi_batch *b, uint8_t strength, const uint8_t
     h263mi_batch::Strengths st;
     RC_TRY(make_strengths(strength, strengths, b->n, /*from_header_allowed=*/false, st));
     DeviceGuard g(b->device);
+    RC_TRY(bound_output_buffers(b, d_rgba, d_deblocked));
     return b->render(st, d_rgba, d_deblocked);
 }
 

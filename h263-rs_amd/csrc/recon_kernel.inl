@@ -438,11 +438,16 @@ H263_DEV uint32_t recon_valid_mask(const ReconArgs &a, const WavePos &p)
 H263_DEV uint32_t recon_block_limit(const ReconArgs &a, const WavePos &p)
 {
     if (!a.coeff_checked) return 1u << 25;
-    // min(pool - cbase, 2^25), 0 when the picture's base lies beyond the pool; in 32-bit pieces so that it stays on
-    // the scalar unit (both values are far below 2^63: the sign of the difference tells which is larger)
-    const uint64_t left = a.coeff_pool_blocks - p.cbase;
+    // min(pool - cbase, 2^25), 0 when the picture's base lies at or beyond the end of the pool; in 32-bit pieces so that it
+    // stays on the scalar unit.  The base comes out of device memory nobody has validated (h263mi_batch_decode[_events]): it
+    // is compared as the unsigned 64-bit number it is -- round 6's GPU fuzzer found that the sign of `pool - cbase` alone lets
+    // a base of 2^64 - 2^20 through (the difference wraps to a small positive number, the block address to 128 MB in FRONT
+    // of the pool: a memory access fault).
+    const uint32_t ch = (uint32_t)(p.cbase >> 32), cl = (uint32_t)p.cbase;
+    const uint32_t ph = (uint32_t)(a.coeff_pool_blocks >> 32), pl = (uint32_t)a.coeff_pool_blocks;
+    if (ch > ph || (ch == ph && cl >= pl)) return 0u;
+    const uint64_t left = a.coeff_pool_blocks - p.cbase;        // 1 .. pool
     const uint32_t hi = (uint32_t)(left >> 32), lo = (uint32_t)left;
-    if ((int32_t)hi < 0) return 0u;
     return (hi || lo > (1u << 25)) ? (1u << 25) : lo;
 }
 

@@ -149,7 +149,9 @@ typedef struct h263mi_picture_desc {
  * pointer lies in (hipMemGetAddressRange; a pointer the runtime does not know is H263MI_ERR_INVALID_ARGUMENT), and the record
  * and base arrays must fit theirs.  A coded block outside the pool or an event list whose bounds do not ascend or reach beyond
  * the events is not read and rejects its stream's picture at the next sync.  The checks cost the 64-stream launch nothing
- * measurable (bench.py: roofline.trusted_mode); the flag is for callers that cannot afford even the look-up. */
+ * measurable (bench.py: roofline.trusted_mode); the flag is for callers that cannot afford even the look-up.  The OUTPUT
+ * buffers of those entry points (d_rgba, d_deblocked) are held to their allocations likewise: one the runtime knows and that
+ * cannot hold the n_streams pictures the launch writes is H263MI_ERR_INVALID_ARGUMENT before anything is queued. */
 #define H263MI_CFG_TRUSTED_ARRAYS 0x4u
 typedef struct h263mi_backend_cfg {
     int32_t  device_id;

@@ -4,6 +4,8 @@ GPU.  Bit-exact for every plane and RGBA byte.  (The GPU parity tests are in tes
 """
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -322,3 +324,41 @@ def test_recon_from_sparse_records_equals_recon_from_dense_records(w, h, events)
     rc, want = orc.decode_picture(w, h, mbs, coeffs, ref)
     st, got = simlib.recon(w, h, mbs, coeffs, ref, events=events, sparse_records=True)
     assert rc == 0 and st == 0 and all((g == e).all() for g, e in zip(got, want))
+
+
+def _hostile_base_script(root):
+    return (
+        "import sys; sys.path[:0]=[%r,%r]\n"
+        "import numpy as np, ctypes as C, simlib, recgen\n"
+        "w,h=64,48\n"
+        "mbs,co=recgen.intra_picture(w,h,seed=3,max_level=40)\n"
+        "mbs=simlib.pad_records(mbs,w,h); L=simlib.layout(w,h)\n"
+        "co=np.ascontiguousarray(co,np.int16).reshape(-1,64)\n"
+        "nz=co!=0; nz[:,0]=False\n"
+        "first=np.zeros(len(co)+1,np.uint32); np.cumsum(nz.sum(axis=1),out=first[1:])\n"
+        "blk,pos=np.nonzero(nz); ev=((co[blk,pos].astype(np.uint16).astype(np.uint32)<<16)|pos.astype(np.uint32))\n"
+        "lib=simlib.lib(asan=True)\n"
+        "for base in BASES:\n"
+        "    for events in (False, True):\n"
+        "        cur=np.full(L.frame_bytes,0xC3,np.uint8); status=np.zeros(1,np.uint32); b=np.array([base],np.uint64)\n"
+        "        dummy=np.zeros((1,64),np.int16)\n"
+        "        if events:\n"
+        "            rc=lib.sim_recon_ex(w,h,1,simlib._p(mbs),simlib._p(dummy),len(co),simlib._p(b),None,0,simlib._p(cur),simlib._p(status),simlib._p(first),simlib._p(ev))\n"
+        "        else:\n"
+        "            rc=lib.sim_recon(w,h,1,simlib._p(mbs),simlib._p(co),len(co),simlib._p(b),None,0,simlib._p(cur),simlib._p(status))\n"
+        "        assert rc==0 and (int(status[0]) & 2), (hex(base), events, rc, int(status[0]))\n"
+        "print('hostile-base-ok')\n" % (root, os.path.join(root, "tests"))).replace(
+            "BASES", "[len(co), len(co)+5, 1<<40, (1<<63)+7, (1<<64)-(1<<20), (1<<64)-2, (1<<64)-1]")
+
+
+def test_a_hostile_coefficient_base_reads_nothing_outside_the_pool():
+    """ReconArgs::coeff_base comes out of a caller's DEVICE memory (h263mi_batch_decode[_events]): nobody has seen its values.
+    A base at, beyond or astronomically beyond the end of the pool -- up to 2^64 - 1, where `pool - base` wraps to a small
+    positive number -- must make every coded block of the picture "outside the pool" (status bit 2) and read NOTHING: run
+    under AddressSanitizer, where a read in front of the pool or of the block offsets is a report.  (Round 6: the GPU fuzzer's
+    hostile arrays found a memory access fault here -- base 2^64 - 1 made block 0 read 128 bytes in FRONT of the pool.)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", _hostile_base_script(root)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "hostile-base-ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])

@@ -306,7 +306,7 @@ def run(budget=60.0, seed=1, verbose=True):
         if rng.random() < (1.0 if os.environ.get("H263MI_FUZZ_MIXED_ONLY") else 0.08):      # (the switch: a run of mixed sets only)
             n_pic, n_px = fuzz_mixed(rng, seed, n_pic, n_px)
             continue
-        if rng.random() < 0.07:
+        if rng.random() < (1.0 if os.environ.get("H263MI_FUZZ_HOSTILE_ONLY") else 0.07):      # (the switch: hostile arrays only)
             n_pic, n_px = fuzz_hostile(rng, min(max(w, 17), 300), min(max(h, 17), 200), seed, n_pic, n_px)
             continue
         if rng.random() < 0.2:

@@ -851,8 +851,13 @@ H263_DEV void coeff_rows_from_events(const ReconArgs &a, ReconWave &s, const Wav
             // reported once per wave).
             if (told) bad = (first > next || next > a.n_events) ? 1u : 0u;
             const uint32_t count = bad ? 0u : next - first;
-            at = first + (uint32_t)r;
-            end = first + (count > 64u ? 64u : count);          // (a block has 64 positions)
+            // (a rejected block starts at 0 with no events: `first + r` would WRAP for a hostile `first` within 8 of 2^32 --
+            // `at` small, `end` huge, and the loop below walks the whole array and beyond.  Round 6's GPU fuzzer found it as a
+            // memory access fault; tests/sim replays it under AddressSanitizer.  A block that passes has first <= next <=
+            // n_events <= 0xffffff00: nothing wraps.)
+            const uint32_t start = bad ? 0u : first;
+            at = start + (uint32_t)r;
+            end = start + (count > 64u ? 64u : count);          // (a block has 64 positions)
         }
         if (told) *bad_events |= bad;
         wave_fence();                                           // zeroed before the first LEVEL lands

@@ -77,6 +77,10 @@ void sim_layout(uint32_t w, uint32_t h, FrameLayout *out) { *out = make_layout(w
 static const uint32_t *g_group_index = nullptr;
 static const uint64_t *g_mb_base = nullptr;
 void sim_set_sparse_records(const uint32_t *group_index, const uint64_t *mb_base) { g_group_index = group_index; g_mb_base = mb_base; }
+// the number of event words the next sim_recon_ex call tells the waves (ReconArgs::n_events: the checked mode of ABI 7's
+// device-array entries); 0xffffffff = not told (the default, restored behind the call)
+static uint32_t g_n_events = 0xffffffffu;
+void sim_set_n_events(uint32_t n) { g_n_events = n; }
 
 int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mbs, const int16_t *coeffs,
                  uint64_t n_blocks, const uint64_t *coeff_base, const uint8_t *ref, int has_ref, uint8_t *cur,
@@ -92,7 +96,8 @@ int sim_recon_ex(uint32_t w, uint32_t h, uint32_t n_pictures, const MbRecord *mb
     a.coeffs = coeffs;
     a.block_first_event = block_first_event;
     a.events = events;
-    a.n_events = 0xffffffffu;                    // (the caller's arrays are built by the tests: only the order is checked)
+    a.n_events = g_n_events;                     // (0xffffffff unless a test says how many: then the bounds are checked too)
+    g_n_events = 0xffffffffu;
     a.coeff_base = coeff_base;
     a.ref = ref ? ref : cur;
     a.cur = cur;

@@ -362,3 +362,17 @@ def test_a_hostile_coefficient_base_reads_nothing_outside_the_pool():
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     out = subprocess.run([sys.executable, "-c", _hostile_base_script(root)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "hostile-base-ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_the_gpu_fuzzers_hostile_arrays_replayed_under_address_sanitizer():
+    """tests/sim/hostile_replay.py: what tools/fuzz_gpu.py's hostile cases hand to a CHECKED launch -- garbage block offsets
+    (0xffffffff: `first + lane` wrapped and the loop walked off the events, a memory access fault on the MI355X in round 6),
+    descending pairs, block indices and bases far outside the pool (2^64 - 2^20: the other fault) -- through the kernel phases
+    on the CPU with exact-size arrays: no read outside them, untouched streams decode, hit streams are rejected or decode
+    something."""
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim", "hostile_replay.py")
+    for seed in ("6", "7", "8", "9"):
+        out = subprocess.run([sys.executable, script, seed, "8"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "hostile-cpu-ok" in out.stdout, (seed, out.stdout[-800:], out.stderr[-3000:])

@@ -155,7 +155,7 @@ def fuzz_hostile(rng, w, h, seed, n_pic, n_px):
         for s_ in hit:
             lo, hi = base[s_], (base[s_ + 1] if s_ + 1 < n else at)
             kind = int(rng.integers(0, 5))
-            junk = [0xffffffff, 0xfffffff0, len(ev), len(ev) + 1, len(ev) + 64, 1 << 28, 0x7fffffff]
+            junk = [0xffffffff, 0xfffffffe, 0xfffffff9, 0xfffffff0, len(ev), len(ev) + 1, len(ev) + 64, 1 << 28, 0x7fffffff]
             # (entries lo and hi of the offsets are shared with the neighbouring streams' blocks: only lo + 1 .. hi - 1 are this
             # stream's own)
             if kind in (0, 1, 4) and hi - lo < 4:
@@ -171,7 +171,7 @@ def fuzz_hostile(rng, w, h, seed, n_pic, n_px):
                 m2["coeff_index"][k] = rng.choice([at, at + 1, 1 << 24, 0xffffffff], size=3)
                 m2["cbp"][k] |= 1
             elif kind == 3:                      # the stream's base beyond the pool
-                b2[s_] = int(rng.choice([at, at + 5, 1 << 40, (1 << 64) - 1]))
+                b2[s_] = [at, at + 5, 1 << 40, (1 << 64) - (1 << 20), (1 << 64) - 1][int(rng.integers(0, 5))]
             else:                                # every offset of the stream shifted far out
                 f2[lo + 1:hi] = (f2[lo + 1:hi].astype(np.uint64) + int(rng.choice([len(ev), 1 << 27]))).astype(np.uint32)
         d = (_dev(m2), _dev(f2), _dev(b2))

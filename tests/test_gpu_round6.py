@@ -391,9 +391,10 @@ def test_arrays_too_small_for_the_batch_are_refused_before_anything_is_queued():
         b.decode(h263mi.PICTURE_I, half.at(both.nbytes + 32), d_c.ptr, base.ptr)        # one record short
     # ... and so are output buffers that cannot hold what the launch writes for the batch's two streams
     small = h263mi.DeviceBuffer(2 * w * h * 4 - 4)
+    small_planes = h263mi.DeviceBuffer(2 * (w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)) - 4)
     for call in (lambda: b.decode(h263mi.PICTURE_I, d_m2.ptr, d_c.ptr, base.ptr, strength=3, d_rgba=small.ptr),
                  lambda: b.render_rgba(3, small.ptr),
-                 lambda: b.render_rgba(3, None, small.ptr)):
+                 lambda: b.render_rgba(3, None, small_planes.ptr)):
         with pytest.raises(h263mi.H263Error) as e:
             call()
         assert e.value.code == h263mi.ERR_INVALID_ARGUMENT

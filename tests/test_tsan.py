@@ -24,7 +24,7 @@ W, H = 176, 144
 @pytest.fixture(scope="module")
 def drivers():
     subprocess.check_call(["make", "-C", TSAN, "-s", "-j2", "all"])
-    return os.path.join(TSAN, "tsan_driver"), os.path.join(TSAN, "tsan_driver_broken")
+    return os.path.join(TSAN, "tsan_driver"), os.path.join(TSAN, "tsan_driver_broken"), os.path.join(TSAN, "asan_driver")
 
 
 @pytest.fixture(scope="module")
@@ -79,3 +79,17 @@ def test_a_deliberately_broken_ordering_is_caught(drivers, corpus):
     r = run(drivers[1], corpus, 1, **SPINNING)
     assert "WARNING: ThreadSanitizer: data race" in r.stderr, r.stderr[-2000:]
     assert r.returncode == 66
+
+
+@pytest.mark.parametrize("mode", ["direct", "packed"])
+def test_host_pipeline_is_clean_under_address_sanitizer(drivers, corpus, mode):
+    """the same driver and scenarios under AddressSanitizer + UBSan: parse-into-staging at per-stream pitches, sparse records,
+    the 2-D copies out of the slot, mixed-set slot moves -- over malloc'd "device" and "pinned" memory, where one byte beyond an
+    allocation is a report (the GPU tests run this code without a sanitizer; the parser alone has its own ASan fuzzer)"""
+    e = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", H263MI_NUMA="0", H263MI_CGROUP_CPU_MAX=corpus[1])
+    if mode == "packed":
+        e["H263MI_DIRECT_WORDS"] = "0"
+    e.pop("LOCAL_WORLD_SIZE", None)
+    r = subprocess.run([drivers[2], corpus[0], "2", "16"], env=e, capture_output=True, text=True, timeout=900)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "0 check failures" in r.stderr, r.stderr[-2000:]

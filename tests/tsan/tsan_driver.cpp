@@ -12,7 +12,7 @@
 //     the workers are met spinning, about to park and parked; under a fake 2-CPU quota (H263MI_CGROUP_CPU_MAX) so that calls
 //     with more threads than the quota take the parking plan (spin 0) and the others the spinning plan;
 //   * pools torn down in the middle of an idle spin and right after a call;
-//   * two batches and a mixed-size set driven from three threads at the same time (distinct objects may be);
+//   * two batches, a mixed-size set and one H263State driven from four threads at the same time (distinct objects may be);
 //   * the packed (H263MI_DIRECT_WORDS=0) transport, and workers that never park (H263MI_SPIN_US = 50 ms, no quota, at most 6
 //     threads: every hand-over goes through the generation word alone, never through the mutex): further runs of the test.
 // Exit code 0 and no ThreadSanitizer report = pass.  The same driver built with -DH263MI_TSAN_BREAK_GENERATION_ORDER (the task is
@@ -150,6 +150,33 @@ static void drive_mixed(unsigned seed, uint32_t n, int calls)
     for (void *p : bufs) CHECK(h263mi_device_free(0, p) == H263MI_OK);
 }
 
+// one H263State fed coded pictures (h263mi_decode_next_picture: parse into the state's own staging slot), with the accessors
+// and the rendering a consumer calls behind it
+static void drive_state(unsigned seed, int pictures)
+{
+    std::mt19937 rng(seed);
+    h263mi_state *st = nullptr;
+    CHECK(h263mi_state_new(H263MI_SORENSON_SPARK_BITSTREAM, nullptr, &st) == H263MI_OK);
+    if (!st) return;
+    std::vector<uint8_t> rgba((size_t)g_w * g_h * 4), y((size_t)g_w * g_h), cb((size_t)g_w * g_h / 4 + 64), cr(cb.size());
+    const std::vector<std::vector<uint8_t>> &stream = g_corpus[seed % g_corpus.size()];
+    for (int k = 0; k < pictures; k++) {
+        const std::vector<uint8_t> &p = stream[(size_t)k % stream.size()];
+        size_t used = 0;
+        CHECK(h263mi_decode_next_picture(st, p.data(), p.size(), &used) == H263MI_OK);
+        h263mi_frame_view v;
+        CHECK(h263mi_get_last_picture(st, &v) == H263MI_OK && v.width == g_w && v.height == g_h);
+        if (rng() % 2) CHECK(h263mi_render_rgba(st, H263MI_STRENGTH_FROM_HEADER, rgba.data()) == H263MI_OK);
+        if (rng() % 4 == 0) CHECK(h263mi_copy_yuv(st, y.data(), cb.data(), cr.data()) == H263MI_OK);
+        if (rng() % 16 == 0) CHECK(h263mi_state_reset(st) == H263MI_OK && (k = (k / (int)stream.size() + 1) * (int)stream.size() - 1, true));
+    }
+    // a truncated picture is that call's error and leaves the state as it was
+    const std::vector<uint8_t> &p0 = stream[0];
+    size_t used = 0;
+    CHECK(h263mi_decode_next_picture(st, p0.data(), 3, &used) != H263MI_OK);
+    h263mi_state_free(st);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2 || !load_corpus(argv[1])) {
@@ -168,9 +195,11 @@ int main(int argc, char **argv)
         std::thread t1(drive_batch, 400 + r, n, 30, true, true);
         std::thread t2(drive_batch, 500 + r, n / 2 + 1, 30, false, false);
         std::thread t3(drive_mixed, 600 + r, n, 20);
+        std::thread t4(drive_state, 700 + r, 40);
         t1.join();
         t2.join();
         t3.join();
+        t4.join();
     }
     const int bad = g_failures.load();
     fprintf(stderr, "tsan_driver: %d rounds, %d check failures\n", rounds, bad);

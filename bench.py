@@ -788,6 +788,9 @@ def main(argv=None):
     import h263mi
     import shard
 
+    # how many ranks of this job share the node (its CPUs, its CPU quota, the cores of each socket): said outright, not left to
+    # the launcher's LOCAL_WORLD_SIZE -- before any batch is made (a batch looks up its host placement when it is created)
+    h263mi.set_ranks_per_node(shard.local_world_size(world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X back-end has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -1086,8 +1089,6 @@ def main(argv=None):
         # every rank runs its own 64 streams end to end, on ITS share of the container's CPUs, all at the same time
         # ... as many parser threads as the LIBRARY chooses for that share (h263mi_default_parser_threads: under a CPU-time
         # quota more threads than the quota has CPUs, parked the moment they run out of work -- include/h263mi.h)
-        # (said outright, not left to the launcher's LOCAL_WORLD_SIZE: the ranks of this job that share the node, shard.py)
-        h263mi.set_ranks_per_node(shard.local_world_size(world))
         threads, quota_per_rank = h263mi.default_parser_threads(n)
         if dist is not None:
             dist.barrier()

@@ -134,3 +134,17 @@ def parse_picture_limited(data, max_w, max_h, options=1):
     f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
     rc = f(a.ctypes.data, ln, options, max_w, max_h, C.byref(words))
     return rc, words.value
+
+
+def parse_picture_events(data, options=1, cap_blocks=120000, cap_events=2000000):
+    """(rc, block_first_event, events) of the product's form of the parse (events only): coded block k of the picture owns
+    events[first[k]:first[k + 1]], each LEVEL << 16 | raster position"""
+    a, ln = _bytes(data)
+    first = np.zeros(cap_blocks + 1, np.uint32)
+    ev = np.zeros(cap_events, np.uint32)
+    nb, ne = C.c_size_t(), C.c_size_t()
+    f = lib().pt_parse_picture_events
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                  C.POINTER(C.c_size_t)]
+    rc = f(a.ctypes.data, ln, options, first.ctypes.data, cap_blocks + 1, ev.ctypes.data, cap_events, C.byref(nb), C.byref(ne))
+    return rc, first[:nb.value + 1].copy(), ev[:ne.value].copy()

@@ -84,6 +84,23 @@ int pt_parse_picture(const uint8_t *data, size_t len, uint32_t options, h263mi_p
     return rc;
 }
 
+// the product's form of the same parse (want_dense = false): block offsets and events (LEVEL << 16 | raster position), for the
+// hand-derived known answers (tests/golden/macroblock_content_known_answers.json)
+int pt_parse_picture_events(const uint8_t *data, size_t len, uint32_t options, uint32_t *first_event, size_t cap_blocks, uint32_t *events,
+                            size_t cap_events, size_t *n_blocks, size_t *n_events)
+{
+    ParsedPicture p;
+    p.want_dense = false;
+    const int rc = parse_picture(data, len, options, nullptr, p);
+    if (rc != H263MI_OK) return rc;
+    *n_blocks = p.n_coded_blocks;
+    *n_events = p.events.size();
+    if (p.n_coded_blocks + 1 > cap_blocks || p.events.size() > cap_events) return H263MI_ERR_INVALID_ARGUMENT;
+    memcpy(first_event, p.block_first_event.data(), (p.n_coded_blocks + 1) * sizeof(uint32_t));
+    if (!p.events.empty()) memcpy(events, p.events.data(), p.events.size() * sizeof(uint32_t));
+    return rc;
+}
+
 // parse_picture with the caller's limit on the picture size (ParsedPicture::size_fits): the return code, and how many 32-bit
 // words the parser's own arrays were sized to -- a picture beyond the limit must not have sized any of them for itself
 static uint32_t g_max_w = 0, g_max_h = 0;

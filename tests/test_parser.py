@@ -193,5 +193,16 @@ def test_macroblocks_with_content_known_answers_derived_from_the_reference_text(
                     assert have == {int(p): v for p, v in blk.items()}, "%s: block %d: %s" % (what, j, have)
             at += len(e["blocks"])
         assert len(co) == at
+        # ... and the EVENTS the product's form of the parse emits (what crosses to the device): block k's events are exactly the
+        # expected (raster position, LEVEL) pairs -- an intra block's DC is not an event
+        rc, first, ev = pl.parse_picture_events(data, options=1)
+        assert rc == 0 and len(first) == at + 1 and first[0] == 0 and first[-1] == len(ev)
+        k = 0
+        for mb in pic["macroblocks"]:
+            for blk in mb["expect"]["blocks"]:
+                if blk is not None:
+                    got = {int(e & 63): int(np.int16(np.uint16(e >> 16))) for e in ev[first[k]:first[k + 1]]}
+                    assert got == {int(p): v for p, v in blk.items()}, (pic["name"], k, got)
+                k += 1
         # the windowed fast paths and the field-by-field transcription agree on these bytes too
         assert pl.compare_parser_paths(data)[0] == 0, pic["name"]

@@ -505,6 +505,18 @@ def test_hand_derived_pictures_with_content_decode_to_what_the_reference_text_gi
         # rendered with what the picture's own header asks for
         assert np.array_equal(st.render_rgba(h263mi.STRENGTH_FROM_HEADER),
                               want_rgba(ref, w, header_strength(pic["quant"], pic["use_deblocker"])))
+    # picture D: ITU-T H.263 (PLUSPTYPE, custom format 32 x 16, 8-bit escape) on a state WITHOUT the Sorenson option
+    d = pics["D"]
+    std = h263mi.H263State(decoder_options=0)
+    std.decode_next_picture(fixture_picture_bytes(d))
+    mbs, co = _fixture_records(d)
+    rc, want = orc.decode_picture(d["width"], d["height"], mbs, co, None)
+    assert rc == 0
+    got = std.get_last_picture()
+    assert (got.width, got.height, got.pquant) == (32, 16, 6)
+    assert_planes_equal(got.as_yuv(), want, d["name"])
+    assert (got.as_luma().reshape(16, 32)[0:8, 8:16] == 101).all() and (got.as_chroma_b() [:8] == 129).all()
+    std.close()
     # the same two pictures through the batch entry (sparse records, events parsed straight into pinned staging)
     bt = h263mi.Batch(3, w, h, pipeline_post=True)
     refs = None

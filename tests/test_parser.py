@@ -166,7 +166,8 @@ def test_macroblocks_with_content_known_answers_derived_from_the_reference_text(
     for pic in gold["pictures"]:
         data = fixture_picture_bytes(pic)
         pl.context_reset()
-        rc, d, mbs, co, used = pl.parse_picture(data, options=1)
+        options = pic.get("decoder_options", 1)          # (1 = SORENSON_SPARK_BITSTREAM; picture D is ITU-T H.263)
+        rc, d, mbs, co, used = pl.parse_picture(data, options=options)
         assert rc == 0, pic["name"]
         assert (d.width, d.height, d.picture_type, d.pquant, d.temporal_reference, d.use_deblocker) == (
             pic["width"], pic["height"], pic["picture_type"], pic["quant"], pic["temporal_reference"], pic["use_deblocker"])
@@ -195,7 +196,7 @@ def test_macroblocks_with_content_known_answers_derived_from_the_reference_text(
         assert len(co) == at
         # ... and the EVENTS the product's form of the parse emits (what crosses to the device): block k's events are exactly the
         # expected (raster position, LEVEL) pairs -- an intra block's DC is not an event
-        rc, first, ev = pl.parse_picture_events(data, options=1)
+        rc, first, ev = pl.parse_picture_events(data, options=options)
         assert rc == 0 and len(first) == at + 1 and first[0] == 0 and first[-1] == len(ev)
         k = 0
         for mb in pic["macroblocks"]:
@@ -205,4 +206,4 @@ def test_macroblocks_with_content_known_answers_derived_from_the_reference_text(
                     assert got == {int(p): v for p, v in blk.items()}, (pic["name"], k, got)
                 k += 1
         # the windowed fast paths and the field-by-field transcription agree on these bytes too
-        assert pl.compare_parser_paths(data)[0] == 0, pic["name"]
+        assert pl.compare_parser_paths(data, options)[0] == 0, pic["name"]

@@ -220,7 +220,7 @@ int sim_post(uint32_t w, uint32_t h, uint32_t n_pictures, const uint8_t *frames,
     a.planes_out = planes_out;
     a.n_pictures = n_pictures;
     a.strength = strength;
-    a.tiles_x = post_tile_columns(a.L.width, &a.wrap);      // as backend.cpp: set_post_tiles
+    a.tiles_x = post_tile_columns(a.L.width, &a.wrap);      // as host_common.h: set_post_tiles
     a.tiles_y = (post_strips_y(h) + POST_STRIPS - 1) / POST_STRIPS;
     a.luma_only = luma_only;
     PostStrip *s = (PostStrip *)aligned_alloc(16, (sizeof(PostStrip) + 15) / 16 * 16);

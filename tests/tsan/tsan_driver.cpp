@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <random>
 #include <thread>
 #include <vector>
@@ -177,6 +178,67 @@ static void drive_state(unsigned seed, int pictures)
     h263mi_state_free(st);
 }
 
+// the entries over DEVICE records (h263mi_batch_decode / _decode_events): the host side of "checked by default" -- sizes not
+// given are taken from the allocations (here: the stub's registry of malloc'd blocks), arrays that cannot hold the batch are
+// refused before anything is queued, H263MI_STRENGTH_FROM_HEADER has no meaning without a header
+static void drive_device_arrays()
+{
+    const uint32_t n = 3;
+    h263mi_backend_cfg cfg{0, H263MI_CFG_PIPELINE_POST, nullptr};
+    h263mi_batch *b = nullptr;
+    CHECK(h263mi_batch_create(n, g_w, g_h, &cfg, &b) == H263MI_OK);
+    if (!b) return;
+    const uint32_t per = h263mi_batch_mbs_per_picture(b);
+    std::vector<h263mi_mb_record> mbs((size_t)n * per);
+    std::vector<int16_t> co((size_t)n * per * 6 * 64);
+    std::vector<uint64_t> base(n);
+    size_t at = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        size_t nb = 0;
+        base[s] = at;
+        CHECK(h263mi_synth_picture_host(H263MI_SYNTH_I_MIXED, g_w, g_h, s, 0, mbs.data() + (size_t)s * per, co.data() + at * 64,
+                                        (size_t)per * 6, &nb) == H263MI_OK);
+        at += nb;
+    }
+    void *d_m = nullptr, *d_c = nullptr, *d_b = nullptr, *d_rgba = nullptr, *d_short = nullptr;
+    CHECK(h263mi_device_malloc(0, mbs.size() * sizeof mbs[0], &d_m) == H263MI_OK);
+    CHECK(h263mi_device_malloc(0, at * 128, &d_c) == H263MI_OK);
+    CHECK(h263mi_device_malloc(0, n * 8, &d_b) == H263MI_OK);
+    CHECK(h263mi_device_malloc(0, (size_t)n * g_w * g_h * 4, &d_rgba) == H263MI_OK);
+    CHECK(h263mi_device_malloc(0, mbs.size() * sizeof mbs[0] - 32, &d_short) == H263MI_OK);
+    CHECK(h263mi_device_memcpy_h2d(0, d_m, mbs.data(), mbs.size() * sizeof mbs[0]) == H263MI_OK);
+    CHECK(h263mi_device_memcpy_h2d(0, d_c, co.data(), at * 128) == H263MI_OK);
+    CHECK(h263mi_device_memcpy_h2d(0, d_b, base.data(), n * 8) == H263MI_OK);
+    const uint8_t strengths[3] = {0, 7, 12};
+    // no size given: the pool ends where its allocation ends
+    CHECK(h263mi_batch_decode_ps(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_m, (const int16_t *)d_c, (const uint64_t *)d_b, 0, 0,
+                                 strengths, (uint8_t *)d_rgba, nullptr) == H263MI_OK);
+    CHECK(h263mi_batch_sync(b) == H263MI_OK);
+    // a size beyond the allocation, records one short, an output buffer too small, a strength out of range, no header to take it from
+    CHECK(h263mi_batch_decode(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_m, (const int16_t *)d_c, (const uint64_t *)d_b, at + 1, 3,
+                              (uint8_t *)d_rgba, nullptr) == H263MI_ERR_INVALID_ARGUMENT);
+    CHECK(h263mi_batch_decode(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_short, (const int16_t *)d_c, (const uint64_t *)d_b, at, 3,
+                              (uint8_t *)d_rgba, nullptr) == H263MI_ERR_INVALID_ARGUMENT);
+    CHECK(h263mi_batch_decode(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_m, (const int16_t *)d_c, (const uint64_t *)d_b, at, 3,
+                              (uint8_t *)d_b, nullptr) == H263MI_ERR_INVALID_ARGUMENT);
+    CHECK(h263mi_batch_decode(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_m, (const int16_t *)d_c, (const uint64_t *)d_b, at, 13,
+                              (uint8_t *)d_rgba, nullptr) == H263MI_ERR_INVALID_ARGUMENT);
+    CHECK(h263mi_batch_decode(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_m, (const int16_t *)d_c, (const uint64_t *)d_b, at,
+                              H263MI_STRENGTH_FROM_HEADER, (uint8_t *)d_rgba, nullptr) == H263MI_ERR_INVALID_ARGUMENT);
+    // a pointer the runtime does not know (host memory) with no size: refused; on a trusted batch: the caller vouches
+    CHECK(h263mi_batch_submit(b, H263MI_PICTURE_I, mbs.data(), co.data(), nullptr) == H263MI_ERR_INVALID_ARGUMENT);
+    h263mi_batch_destroy(b);
+    cfg.flags |= H263MI_CFG_TRUSTED_ARRAYS;
+    CHECK(h263mi_batch_create(n, g_w, g_h, &cfg, &b) == H263MI_OK);
+    if (b) {
+        CHECK(h263mi_batch_decode(b, H263MI_PICTURE_I, (const h263mi_mb_record *)d_short, (const int16_t *)d_c, (const uint64_t *)d_b, 0, 3,
+                                  (uint8_t *)d_rgba, nullptr) == H263MI_OK);       // (stub kernels read nothing of it)
+        CHECK(h263mi_batch_sync(b) == H263MI_OK);
+        h263mi_batch_destroy(b);
+    }
+    for (void *p : {d_m, d_c, d_b, d_rgba, d_short}) CHECK(h263mi_device_free(0, p) == H263MI_OK);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2 || !load_corpus(argv[1])) {
@@ -186,6 +248,7 @@ int main(int argc, char **argv)
     const int rounds = argc > 2 ? atoi(argv[2]) : 2;
     if (argc > 3) g_max_threads = (uint32_t)atoi(argv[3]);
     const uint32_t n = (uint32_t)g_corpus.size();
+    drive_device_arrays();
     for (int r = 0; r < rounds; r++) {
         // one batch after the other: spinning and parking plans, teardown parked and mid-spin
         drive_batch(100 + r, n, 40, /*pipeline=*/true, /*destroy_mid_spin=*/false);

@@ -376,3 +376,17 @@ def test_the_gpu_fuzzers_hostile_arrays_replayed_under_address_sanitizer():
     for seed in ("6", "7", "8", "9"):
         out = subprocess.run([sys.executable, script, seed, "8"], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "hostile-cpu-ok" in out.stdout, (seed, out.stdout[-800:], out.stderr[-3000:])
+
+
+def test_garbage_record_fields_and_event_words_under_address_sanitizer():
+    """tests/sim/garbage_fields_replay.py: WHAT a checked launch reads may be anything -- macroblock types 6..255, quantisers 0
+    and 32..255, any coded-block-pattern and kill byte, vectors over the whole int16 range, INTRADC codes that never occur,
+    event words with positions beyond 63 -- P pictures on a reference and I pictures, both transports: no access outside the
+    caller's arrays and the frame store (exact-size arrays under AddressSanitizer, array indices under UBSan), and the streams
+    left alone decode to the oracle's planes.  (tools/fuzz_gpu.py: fuzz_garbage_fields is the same on the MI355X.)"""
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim", "garbage_fields_replay.py")
+    for seed in ("11", "12", "13"):
+        out = subprocess.run([sys.executable, script, seed, "10"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "garbage-fields-cpu-ok" in out.stdout, (seed, out.stdout[-800:], out.stderr[-3000:])

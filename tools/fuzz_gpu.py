@@ -197,6 +197,130 @@ def fuzz_hostile(rng, w, h, seed, n_pic, n_px):
     return n_pic, n_px
 
 
+def fuzz_garbage_fields(rng, w, h, seed, n_pic, n_px):
+    """GARBAGE record fields and event / coefficient words (tests/sim/garbage_fields_replay.py is the same on the CPU under
+    AddressSanitizer): macroblock types 6..255, quantisers 0 and 32..255, any coded-block-pattern and kill byte, vectors over
+    the whole int16 range, INTRADC codes that never occur, event words with positions beyond 63 and LEVELs over the whole int16
+    range -- in P pictures on a reference and in I pictures, both transports, checked launches with no sizes given.  Nothing
+    may fault; streams left alone decode to the oracle's planes; a stream that was hit is rejected or decodes SOMETHING; the
+    batch decodes clean pictures afterwards."""
+    import simlib
+    n = int(rng.choice([1, 2, 5, 8]))
+    inter, events = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    b = h263mi.Batch(n, w, h, pipeline_post=bool(rng.integers(0, 2)))
+    what = ("garbage fields", w, h, n, inter, events, seed)
+
+    def picture(make):
+        recs, at, base = [], 0, []
+        for s_ in range(n):
+            m, c = make(s_)
+            m = simlib.pad_records(m, w, h)
+            bi = np.zeros(len(c), bool)
+            for r in m:
+                if int(r["mb_type"]) in (3, 4):
+                    k = int(r["coeff_index"])
+                    bi[k:k + bin(int(r["cbp"])).count("1")] = True
+            recs.append((m, c, bi))
+            base.append(at)
+            at += len(c)
+        mbs = np.concatenate([r[0] for r in recs])
+        co = np.concatenate([r[1] for r in recs]) if at else np.zeros((0, 64), np.int16)
+        first, ev = h263mi.events_from_dense(co, np.concatenate([r[2] for r in recs]) if at else None)
+        return {"mbs": mbs, "co": co if at else np.zeros((1, 64), np.int16), "first": first,
+                "ev": ev if len(ev) else np.zeros(4, np.uint32), "base": base, "at": at}
+
+    seeds = [int(v) for v in rng.integers(0, 1 << 30, 2 * n)]
+    key = picture(lambda s_: recgen.intra_picture(w, h, seed=seeds[s_], max_level=int(rng.choice([40, 1023]))))
+    key_out = []
+    for s_ in range(n):
+        lo, hi = key["base"][s_], (key["base"][s_ + 1] if s_ + 1 < n else key["at"])
+        per = len(key["mbs"]) // n
+        m = key["mbs"][s_ * per:(s_ + 1) * per]                  # (block indices are relative to the stream's base)
+        rc, out = orc.decode_picture(w, h, m, key["co"][lo:hi] if hi > lo else np.zeros((0, 64), np.int16), None)
+        assert rc == 0
+        key_out.append(out)
+    target, want = key, key_out
+    if inter:
+        target = picture(lambda s_: recgen.inter_picture(w, h, seed=seeds[n + s_], mv_range=32, p_4v=0.3, p_intra=0.15, p_coded=0.5,
+                                                          quant=0, max_level=60, sparse_low=False))
+        want = []
+        per = len(target["mbs"]) // n
+        for s_ in range(n):
+            lo, hi = target["base"][s_], (target["base"][s_ + 1] if s_ + 1 < n else target["at"])
+            rc, out = orc.decode_picture(w, h, target["mbs"][s_ * per:(s_ + 1) * per],
+                                         target["co"][lo:hi] if hi > lo else np.zeros((0, 64), np.int16), key_out[s_])
+            assert rc == 0
+            want.append(out)
+
+    def submit(pic, ptype, mbs=None, co=None, ev=None):
+        d = [_dev(pic["mbs"] if mbs is None else mbs), _dev(np.array(pic["base"], np.uint64))]
+        if events:
+            d += [_dev(pic["first"]), _dev(pic["ev"] if ev is None else ev)]
+            b.decode_events(ptype, d[0].ptr, d[2].ptr, d[3].ptr, d[1].ptr)
+        else:
+            d += [_dev(pic["co"] if co is None else co)]
+            b.decode(ptype, d[0].ptr, d[2].ptr, d[1].ptr)
+        rcs = b.sync_streams()
+        for x in d:
+            x.free()
+        return rcs
+
+    def clean():
+        if any(submit(key, h263mi.PICTURE_I)):
+            raise FuzzMismatch("clean key picture rejected: %r" % (what,))
+
+    def check(rcs, hit, attempt):
+        for s_ in range(n):
+            if s_ in hit:
+                if rcs[s_] not in (0, h263mi.ERR_INVALID_ARGUMENT, h263mi.ERR_UNCODED_IFRAME_BLOCKS):
+                    raise FuzzMismatch("hit stream %d: verdict %d: %r" % (s_, rcs[s_], what))
+                continue
+            if rcs[s_] != 0:
+                raise FuzzMismatch("untouched stream %d rejected (%d): %r attempt %d" % (s_, rcs[s_], what, attempt))
+            for g, e, name in zip(b.copy_yuv(s_), want[s_], "Y Cb Cr".split()):
+                if not (np.asarray(g) == e).all():
+                    raise FuzzMismatch("untouched stream %d differs: %r attempt %d %s" % (s_, what, attempt, name))
+
+    ptype = h263mi.PICTURE_P if inter else h263mi.PICTURE_I
+    per = len(target["mbs"]) // n
+    for attempt in range(int(rng.integers(2, 6))):
+        clean()
+        if attempt == 0:
+            check(submit(target, ptype), set(), -1)              # the picture as it is: every stream decodes
+            clean()
+        hit = set(int(v) for v in rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False))
+        m2, e2, c2 = target["mbs"].copy(), target["ev"].copy(), target["co"].copy()
+        first, base, at = target["first"], target["base"], target["at"]
+        for s_ in hit:
+            kind = int(rng.integers(0, 7))
+            k = s_ * per + rng.integers(0, per, size=max(1, per // 3))
+            lo, hi = base[s_], (base[s_ + 1] if s_ + 1 < n else at)
+            if kind == 0:
+                m2["mb_type"][k] = rng.integers(6, 256, size=len(k))
+            elif kind == 1:
+                m2["quant"][k] = rng.choice([0, 32, 127, 128, 255], size=len(k))
+            elif kind == 2:                      # (more coded blocks than the macroblock has: into the next one's, or past the pool)
+                m2["cbp"][k] = rng.integers(0, 256, size=len(k))
+                m2["kill"][k] = rng.integers(0, 256, size=len(k))
+            elif kind == 3:
+                m2["mv"][k] = rng.choice([-32768, -32767, -4097, -1025, 1024, 4096, 32766, 32767], size=(len(k), 4, 2))
+            elif kind == 4:
+                m2["intradc"][k] = rng.choice([0, 128, 255], size=(len(k), 6))
+                m2["reserved"][k] = 255
+            elif events and first[hi] > first[lo]:
+                j = rng.integers(int(first[lo]), int(first[hi]), size=16)
+                e2[j] = rng.integers(0, 1 << 32, size=16, dtype=np.uint64).astype(np.uint32)
+            elif hi > lo:
+                j = rng.integers(lo, hi, size=4)
+                c2[j] = rng.integers(-32768, 32768, size=(4, 64))
+        check(submit(target, ptype, m2, c2, e2), hit, attempt)
+        n_pic += 2 * n
+        n_px += 2 * n * w * h
+    clean()
+    b.close()
+    return n_pic, n_px
+
+
 def fuzz_mixed(rng, seed, n_pic, n_px):
     """A set of streams of different (and changing) picture sizes behind one call (h263mi_mixed): per call every stream
     does one of -- nothing, a P picture, a key frame of its size, a key frame of ANOTHER size (the stream moves), a P picture
@@ -308,6 +432,9 @@ def run(budget=60.0, seed=1, verbose=True):
             continue
         if rng.random() < (1.0 if os.environ.get("H263MI_FUZZ_HOSTILE_ONLY") else 0.07):      # (the switch: hostile arrays only)
             n_pic, n_px = fuzz_hostile(rng, min(max(w, 17), 300), min(max(h, 17), 200), seed, n_pic, n_px)
+            continue
+        if rng.random() < (1.0 if os.environ.get("H263MI_FUZZ_GARBAGE_ONLY") else 0.05):      # (the switch: garbage fields only)
+            n_pic, n_px = fuzz_garbage_fields(rng, min(max(w, 17), 300), min(max(h, 17), 200), seed, n_pic, n_px)
             continue
         if rng.random() < 0.2:
             # a BATCH of streams in lock step (h263mi_batch_decode / _decode_events), plain or frame-pipelined: the launch

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <memory>
 #include <random>
 #include <thread>
 #include <vector>
@@ -239,6 +240,117 @@ static void drive_device_arrays()
     for (void *p : {d_m, d_c, d_b, d_rgba, d_short}) CHECK(h263mi_device_free(0, p) == H263MI_OK);
 }
 
+// the entries over HOST arrays of a caller (h263mi_submit_picture[_events], h263mi_batch_submit_host[_events]) fed GARBAGE: every
+// record field, block index, block offset and event word random, in exact-size heap arrays (AddressSanitizer sees one element
+// beyond them).  The host validates these before anything is staged: the answer is a refusal or -- garbage that happens to be a
+// valid picture -- a decode; never a read outside the arrays, never a changed state behind a refusal.
+static void drive_host_garbage(unsigned seed, int tries)
+{
+    std::mt19937 rng(seed);
+    h263mi_state *st = nullptr;
+    CHECK(h263mi_state_new(H263MI_SORENSON_SPARK_BITSTREAM, nullptr, &st) == H263MI_OK);
+    h263mi_backend_cfg cfg{0, 0, nullptr};
+    h263mi_batch *b = nullptr;
+    CHECK(h263mi_batch_create(2, g_w, g_h, &cfg, &b) == H263MI_OK);
+    if (!st || !b) return;
+    const uint32_t per = h263mi_batch_mbs_per_picture(b);
+    // a valid key picture first: garbage P pictures then have a reference to be refused against, or to predict from
+    std::vector<h263mi_mb_record> key(per);
+    std::vector<int16_t> key_co((size_t)per * 6 * 64);
+    size_t key_blocks = 0;
+    CHECK(h263mi_synth_picture_host(H263MI_SYNTH_I_MIXED, g_w, g_h, 0, 0, key.data(), key_co.data(), (size_t)per * 6, &key_blocks) == H263MI_OK);
+    h263mi_picture_desc desc{};
+    desc.width = g_w;
+    desc.height = g_h;
+    desc.picture_type = H263MI_PICTURE_I;
+    desc.pquant = 8;
+    CHECK(h263mi_submit_picture(st, &desc, key.data(), per, key_co.data(), key_blocks) == H263MI_OK);
+    auto acceptable = [](int rc) {
+        return rc == H263MI_OK || rc == H263MI_ERR_INVALID_ARGUMENT || rc == H263MI_ERR_UNCODED_IFRAME_BLOCKS ||
+               rc == H263MI_ERR_PICTURE_FORMAT_INVALID;
+    };
+    int refused = 0, taken = 0;
+    for (int t = 0; t < tries; t++) {
+        const int flavour = (int)(rng() % 4);      // 0: all random; 1: plausible fields, random structure; 2, 3: a valid picture
+                                                   // with (2) or without (3) a few wild fields
+        const size_t n_mbs = rng() % 3 == 0 ? per : rng() % (per + 1);
+        const size_t n_blocks = rng() % 40;
+        // exact-size arrays (new[]: a redzone right behind the last element)
+        std::unique_ptr<uint32_t[]> first(new uint32_t[n_blocks + 1]);
+        uint32_t at = 0;
+        for (size_t k = 0; k <= n_blocks; k++) {
+            first[k] = flavour ? at : rng();
+            at += (uint32_t)(rng() % 9);
+        }
+        const size_t n_events = flavour >= 2 ? first[n_blocks] : rng() % 200;
+        if (flavour == 1 && rng() % 2) first[n_blocks] = (uint32_t)n_events;
+        std::unique_ptr<h263mi_mb_record[]> mbs(new h263mi_mb_record[n_mbs ? n_mbs : 1]);
+        std::unique_ptr<int16_t[]> co(new int16_t[(n_blocks ? n_blocks : 1) * 64]);
+        std::unique_ptr<uint32_t[]> ev(new uint32_t[n_events ? n_events : 1]);
+        const uint32_t wild = flavour == 3 ? 0u : (uint32_t)(flavour == 2 ? 2 * per : 50);       // (a wild value in one field of `wild`)
+        for (size_t i = 0; i < n_mbs; i++) {
+            h263mi_mb_record &m = mbs[i];
+            uint32_t *w = reinterpret_cast<uint32_t *>(&m);
+            for (size_t k = 0; k < sizeof m / 4; k++) w[k] = rng();
+            if (flavour) {
+                m.mb_type = (uint8_t)(rng() % 6);
+                m.quant = (uint8_t)(1 + rng() % 31);
+                m.cbp &= 0x3f;
+                m.kill &= 0x3f;
+                m.coeff_index = n_blocks ? (uint32_t)(rng() % n_blocks) : 0;
+                if (flavour >= 2) {
+                    if (n_blocks < 6) m.cbp = 0;
+                    else m.coeff_index = (uint32_t)(rng() % (n_blocks - 5));
+                }
+                if (wild && rng() % wild == 0) m.coeff_index = rng() % 2 ? 0xffffffffu : (uint32_t)n_blocks;
+                if (wild && rng() % wild == 0) m.quant = (uint8_t)(rng() % 2 ? 0 : 32);
+                if (wild && rng() % wild == 0) m.mb_type = (uint8_t)(6 + rng() % 250);
+                if (wild && rng() % wild == 0) m.cbp |= 0x40;
+            }
+        }
+        for (size_t k = 0; k < (n_blocks ? n_blocks : 1) * 64; k++) co[k] = (int16_t)rng();
+        for (size_t k = 0; k < n_events; k++) ev[k] = rng();
+        if (flavour >= 2)                                  // a block's events name distinct positions
+            for (size_t k = 0; k < n_blocks; k++)
+                for (uint32_t e = first[k]; e < first[k + 1]; e++) ev[e] = (ev[e] & 0xffff0000u) | ((first[k] + 7u * (e - first[k])) & 63u);
+        if (flavour == 2 && n_blocks && rng() % 3 == 0) first[rng() % (n_blocks + 1)] = rng() % 2 ? 0xffffffffu : (uint32_t)n_events + 1;
+        if (flavour == 2 && n_events && rng() % 3 == 0) ev[rng() % n_events] = ev[0];
+        desc.picture_type = (uint8_t)(flavour >= 2 ? rng() % 2 : rng() % 12);
+        if (flavour < 3 && rng() % 20 == 0) desc.width = (uint16_t)rng();
+        else desc.width = g_w;
+        h263mi_frame_view before{}, after{};
+        const int had = h263mi_get_last_picture(st, &before);
+        int rc = rng() % 2 ? h263mi_submit_picture(st, &desc, mbs.get(), n_mbs, co.get(), n_blocks)
+                           : h263mi_submit_picture_events(st, &desc, mbs.get(), n_mbs, first.get(), n_blocks, ev.get(), n_events);
+        CHECK(acceptable(rc));
+        if (rc != H263MI_OK) {
+            refused++;
+            // state.rs:142: on error the state is unchanged
+            CHECK(h263mi_get_last_picture(st, &after) == had && (had != H263MI_OK || (after.width == before.width && after.dev_y == before.dev_y && after.temporal_reference == before.temporal_reference)));
+        } else {
+            taken++;
+        }
+        // the batch forms: stream 0 the garbage, stream 1 the key picture (or nothing)
+        const h263mi_mb_record *bm[2] = {mbs.get(), key.data()};
+        const uint32_t bn[2] = {(uint32_t)n_mbs, per};
+        const int16_t *bc[2] = {co.get(), key_co.data()};
+        const uint32_t bb[2] = {(uint32_t)n_blocks, (uint32_t)key_blocks};
+        rc = h263mi_batch_submit_host(b, H263MI_PICTURE_I, bm, bn, bc, bb);
+        CHECK(acceptable(rc));
+        const uint32_t *bf[2] = {first.get(), nullptr};
+        const uint32_t *be[2] = {ev.get(), nullptr};
+        const uint32_t bn0[2] = {(uint32_t)n_mbs, 0}, bb0[2] = {(uint32_t)n_blocks, 0}, bne[2] = {(uint32_t)n_events, 0};
+        const h263mi_mb_record *bm0[2] = {mbs.get(), nullptr};
+        rc = h263mi_batch_submit_host_events(b, H263MI_PICTURE_I, bm0, bn0, bf, bb0, be, bne);
+        CHECK(acceptable(rc));
+        (void)h263mi_batch_sync(b);
+    }
+    CHECK(refused > 0);
+    fprintf(stderr, "  host garbage: %d refused, %d decoded\n", refused, taken);
+    h263mi_batch_destroy(b);
+    h263mi_state_free(st);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2 || !load_corpus(argv[1])) {
@@ -249,6 +361,7 @@ int main(int argc, char **argv)
     if (argc > 3) g_max_threads = (uint32_t)atoi(argv[3]);
     const uint32_t n = (uint32_t)g_corpus.size();
     drive_device_arrays();
+    drive_host_garbage(900, 400);
     for (int r = 0; r < rounds; r++) {
         // one batch after the other: spinning and parking plans, teardown parked and mid-spin
         drive_batch(100 + r, n, 40, /*pipeline=*/true, /*destroy_mid_spin=*/false);
